@@ -1,0 +1,177 @@
+/* mtr_engine.h — C ABI of the MI355X batch metering engine (libmtr_engine.so).
+ *
+ * This is the drop-in boundary for the per-sample DSP hot path of x42/meters.lv2.
+ * The reference has no FFI of its own: its L1 DSP layer is a set of C++ classes
+ * (namespace LV2M) plus the C structs of src/spectr.c, called once per audio block
+ * from the LV2 run() functions.  Each entry point below names the reference
+ * interface it replaces; INTEGRATION.md shows the binding a maintainer would add
+ * in src/ebulv2.cc / src/meters.cc / src/spectrumlv2.c.
+ *
+ * One engine = `n_streams` independent stereo streams advancing in lock step
+ * (the batched many-stream variant of one plugin instance each).  The LV2 shim
+ * (lib/meters_amd.so, include/lv2_min.h) is a thin n_streams = 1 client.
+ *
+ * Plain C: opaque handle, int status returns, plain pointers and sizes, no
+ * exceptions and no torch/HIP types in any signature (`hip_stream` is a
+ * hipStream_t passed as void*, NULL = the default stream).
+ */
+#ifndef MTR_ENGINE_H
+#define MTR_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTR_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define MTR_OK               0
+#define MTR_ERR_ARG         -1   /* NULL / out-of-range argument */
+#define MTR_ERR_UNSUPPORTED -2   /* configuration this build does not implement */
+#define MTR_ERR_NODEVICE    -3   /* no usable HIP device: the engine never falls back to the CPU */
+#define MTR_ERR_HIP         -4   /* a HIP runtime call failed; see mtr_last_error() */
+#define MTR_ERR_NOMEM       -5
+
+/* ---- meters (bit mask) --------------------------------------------------- */
+#define MTR_METER_EBU        0x01u  /* Ebu_r128_proc: K-weighting + gated loudness  (ebumeter/ebu_r128_proc.cc) */
+#define MTR_METER_TRUEPEAK   0x02u  /* TruePeakdsp::process_max: 4x true peak       (jmeters/truepeakdsp.cc:101-124) */
+#define MTR_METER_SPECTR30   0x04u  /* 30-band 1/3-octave bank                      (src/spectr.c, src/spectrumlv2.c) */
+#define MTR_METER_TPBALLIST  0x08u  /* TruePeakdsp::process: PPM-style ballistics   (jmeters/truepeakdsp.cc:41-99) */
+#define MTR_METER_BITSTATS   0x10u  /* float_stats                                   (src/bitmeter.c:63-105) */
+#define MTR_METER_SIGDIST    0x20u  /* signal distribution histogram                (src/sigdistlv2.c:303-318) */
+
+#define MTR_HIST_LEN   751          /* src/uris.h:45  HIST_LEN */
+#define MTR_NBANDS     30           /* src/spectrumlv2.c:33  FILTER_COUNT */
+#define MTR_BIM_LAST   584          /* src/uris.h:60 */
+#define MTR_DIST_BIN   361          /* src/uris.h:47 */
+
+typedef struct mtr_engine mtr_engine;
+
+typedef struct {
+	uint32_t struct_size;    /* = sizeof(mtr_config) */
+	uint32_t meters;         /* MTR_METER_* mask */
+	uint32_t n_streams;      /* independent streams in the batch (>= 1) */
+	uint32_t n_channels;     /* 2 (interleaved stereo frames) or 1 (mono; SPECTR30 / TPBALLIST only) */
+	float    sample_rate;    /* Hz; reference: instantiate()'s `rate` (src/meters.cc:194) */
+	int32_t  device;         /* HIP device ordinal */
+	uint32_t max_frames;     /* largest n_frames a process call will carry (scratch sizing); 0 = grow on demand */
+	uint32_t tune_run;       /* frames per lane run of the fused kernel: 0 = auto, else 13 or 39 */
+	uint32_t tune_segments;  /* time segments per stream per call: 0 = auto */
+	uint32_t reserved[3];
+} mtr_config;
+
+/* Per-stream results.  The first nine floats are Ebu_r128_proc's getters in
+ * declaration order (ebumeter/ebu_r128_proc.h:81-89), then the two histogram
+ * counts (:93-94). */
+typedef struct {
+	float   loudness_M, maxloudn_M, loudness_S, maxloudn_S;
+	float   integrated, integ_thr, range_min, range_max, range_thr;
+	int32_t hist_M_count, hist_S_count;
+	float   truepeak[2];       /* max |4x-oversampled sample| since reset, per channel, linear:
+	                            * the max-hold of TruePeakdsp::read() the LV2 glue keeps (src/ebulv2.cc:361-365) */
+	float   truepeak_call[2];  /* the same over the most recent process call only = process_max() + read() */
+	float   tpb_level[2];      /* TPBALLIST: TruePeakdsp::read(m, p) after the most recent call: m (src/meters.cc:491-507) */
+	float   tpb_peak[2];       /*            ... and p, the raw true peak of that call */
+} mtr_stream_result;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+
+/* replaces: new Ebu_r128_proc + init(2, rate) (src/ebulv2.cc:189-190), new TruePeakdsp + init(rate)
+ * x2 (:192-196), bandpass_setup x30 (src/spectrumlv2.c:103-118), per stream. */
+int  mtr_engine_create (const mtr_config* cfg, mtr_engine** out);
+/* replaces: delete ebu / delete mtr[c] (src/ebulv2.cc:500-512), spectrum_cleanup */
+void mtr_engine_destroy (mtr_engine* e);
+
+/* replaces: Ebu_r128_proc::reset (ebu_r128_proc.cc:176-189) + TruePeakdsp::reset + zeroed bank state */
+int  mtr_engine_reset (mtr_engine* e);
+/* replaces: Ebu_r128_proc::integr_start / integr_pause / integr_reset (ebu_r128_proc.h:77-79, .cc:192-204) */
+int  mtr_engine_integr_start (mtr_engine* e);
+int  mtr_engine_integr_pause (mtr_engine* e);
+int  mtr_engine_integr_reset (mtr_engine* e);
+/* replaces: TruePeakdsp::reset on every stream (src/meters.cc:451-456) */
+int  mtr_engine_truepeak_reset (mtr_engine* e);
+/* replaces: the speed-port handler (src/spectrumlv2.c:170-177) and the peak-hold reset (:191-205) */
+int  mtr_engine_spectr_set_speed (mtr_engine* e, float v);
+int  mtr_engine_spectr_reset_peak (mtr_engine* e);
+
+/* ---- the hot path --------------------------------------------------------- */
+
+/* Advance every stream by n_frames.  `d_audio` is DEVICE memory, stream s at
+ * d_audio + s * stream_stride_frames * n_channels, frames interleaved [L R].
+ * Asynchronous on `hip_stream`.
+ * replaces, per stream: Ebu_r128_proc::process (ebu_r128_proc.cc:207-248) as called at
+ * src/ebulv2.cc:341-342, TruePeakdsp::process_max x2 (:344-347), the per-sample loop of
+ * spectrum_run (src/spectrumlv2.c:210-227), TruePeakdsp::process (src/meters.cc:465-475). */
+int  mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_frames,
+                                uint64_t stream_stride_frames, void* hip_stream);
+/* Same with HOST memory (copied to the device first; PCIe-bound, not the benchmarked path). */
+int  mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_frames,
+                              uint64_t stream_stride_frames);
+/* n_streams == 1, planar host channels — the shape an LV2 run() hands over
+ * (src/meters.cc:298-299: one float* per port, n_samples frames). */
+int  mtr_engine_process_planar_host (mtr_engine* e, const float* const* channels, uint32_t n_frames);
+
+/* Wait for everything queued by process calls. */
+int  mtr_engine_sync (mtr_engine* e);
+
+/* ---- results (synchronise, then copy to host memory) ----------------------- */
+
+/* replaces: loudness_M() ... range_thr(), hist_*_count() (ebu_r128_proc.h:81-94), TruePeakdsp::read */
+int  mtr_engine_results (mtr_engine* e, uint32_t first, uint32_t count, mtr_stream_result* out);
+/* replaces: histogram_M() / histogram_S() (ebu_r128_proc.h:91-92); out arrays are [count][751] */
+int  mtr_engine_histograms (mtr_engine* e, uint32_t first, uint32_t count, int32_t* hist_M, int32_t* hist_S);
+/* Per-fragment mean powers of the most recent call ([count][n_frag], n_frag returned), i.e. the
+ * values Ebu_r128_proc::process pushes into _power[] (ebu_r128_proc.cc:219). Diagnostic / parity. */
+int  mtr_engine_fragment_powers (mtr_engine* e, uint32_t first, uint32_t count, float* out,
+                                 uint32_t capacity_per_stream, uint32_t* n_frag);
+/* replaces: spectrum_run's epilogue (src/spectrumlv2.c:230-248): raw val_f / max_f and the dB
+ * values written to ports 0-29 / 30-59; arrays are [count][30], any may be NULL */
+int  mtr_engine_spectrum (mtr_engine* e, uint32_t first, uint32_t count,
+                          float* val, float* max, float* val_db, float* max_db);
+
+/* ---- multi-GPU aggregate ---------------------------------------------------- */
+
+/* Sum the two loudness histograms over this engine's streams into d_hist[2][751] (int32) and take
+ * the max of true peak / max-M / max-S into d_max[4] = {tp_L, tp_R, maxM, maxS} — both DEVICE
+ * buffers owned by the caller, so the host can all-reduce them across ranks (RCCL) in place.
+ * No reference counterpart (the reference is single-instance). */
+int  mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, void* hip_stream);
+/* Programme-level integrated loudness / range from (summed) histograms, exactly as
+ * Ebu_r128_hist::calc_integ / calc_range do (ebu_r128_proc.cc:105-150). Host-side, pure C. */
+void mtr_hist_loudness (const int32_t* hist_M, const int32_t* hist_S,
+                        float* integrated, float* integ_thr,
+                        float* range_min, float* range_max, float* range_thr);
+
+/* ---- measurement / introspection --------------------------------------------- */
+
+/* HIP-event timing of the kernels the engine launches (off by default). */
+int  mtr_engine_timing_enable (mtr_engine* e, int on);
+/* Sum over the process calls since the last query: fused K-weight+true-peak kernel, gating kernel,
+ * filter-bank kernel (ms) and the number of calls. Synchronises. */
+int  mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, float* ms_bank, uint32_t* calls);
+/* K-weighting coefficients a0 a1 a2 b1 b2 c3 c4 at `sample_rate` (Ebu_r128_proc::detect_init,
+ * ebumeter/ebu_r128_proc.cc:263-293) */
+int  mtr_kweight_coef (float sample_rate, float* out7);
+/* the 120-float polyphase table (Resampler_table ctor, fr = 1, hl = 24, np = 4) */
+int  mtr_fir_table (float* out120);
+/* 36 doubles [section][a0 a1 a2 b0 b1 b2] of band `band` at `rate` (bandpass_setup, src/spectr.c:89-206) */
+int  mtr_band_coef (double rate, uint32_t band, double* out36);
+
+/* Fill device memory with the repo's seeded synthetic programme signal:
+ * stream s = LCG(seed + s) noise under a slow envelope plus a tone. Used by bench.py so the
+ * timed region starts with inputs resident in HBM. */
+int  mtr_synth_fill_device (float* d_audio, uint32_t n_streams, uint64_t n_frames,
+                            uint64_t stream_stride_frames, uint32_t seed, float sample_rate,
+                            int kind, void* hip_stream);
+
+const char* mtr_last_error (void);
+const char* mtr_version (void);
+int         mtr_abi_version (void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,603 @@
+// mtr_engine.hip — host side of libmtr_engine.so: the C ABI of include/mtr_engine.h.
+//
+// Owns device state for `n_streams` lock-step streams, turns each process call into a tiling
+// plan (tiles never cross 50 ms fragment boundaries; time segments give the fused kernel enough
+// independent waves when the batch is small) and launches the HIP kernels on the caller's
+// stream.  There is no CPU fallback anywhere in this file: without a HIP device create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mtr_internal.h"
+
+static thread_local std::string g_err;
+
+static int fail (int code, const char* what, hipError_t he = hipSuccess)
+{
+	char buf[256];
+	if (he != hipSuccess) snprintf (buf, sizeof (buf), "%s: %s", what, hipGetErrorString (he));
+	else                  snprintf (buf, sizeof (buf), "%s", what);
+	g_err = buf;
+	return code;
+}
+
+#define HIPCHK(call) do { hipError_t he_ = (call); if (he_ != hipSuccess) return fail (MTR_ERR_HIP, #call, he_); } while (0)
+
+template <typename T> struct DevBuf {
+	T*     p = nullptr;
+	size_t n = 0;
+	int reserve (size_t want) {
+		if (want <= n) return 0;
+		if (p) (void) hipFree (p);
+		p = nullptr; n = 0;
+		if (hipMalloc ((void**) &p, want * sizeof (T)) != hipSuccess) return -1;
+		n = want;
+		return 0;
+	}
+	void release () { if (p) (void) hipFree (p); p = nullptr; n = 0; }
+};
+
+struct Plan {
+	uint64_t n_frames = 0;
+	uint32_t frcnt_in = 0;      // frames left in the open fragment when the call starts
+	uint32_t frcnt_out = 0;
+	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0;
+	bool     valid = false;
+};
+
+struct mtr_engine {
+	mtr_config cfg;
+	int      run = 13;            // K: frames per lane run
+	uint32_t fragm = 0;           // frames per 50 ms fragment
+	uint32_t frcnt = 0;           // frames remaining in the open fragment (all streams in lock step)
+	bool     integr = false;
+	float    kw[7];
+	float    omega = 0.f;
+	hipStream_t last_stream = nullptr;
+
+	DevBuf<mtr_stream_state> state;
+	DevBuf<int32_t>  hist;
+	DevBuf<float>    fir_hist[2];   // ping-pong 47-frame history
+	int              hist_cur = 0;
+	DevBuf<float>    scan_m, bin_power, tile_power, frag_power, stage;
+	DevBuf<uint32_t> tile_start, seg_tile, frag_tile;
+	DevBuf<double>   bank_coef, bank_z;
+	DevBuf<float>    bank_val, bank_max;
+	DevBuf<int32_t>  bank_ac;
+	Plan             plan;
+	uint32_t         last_n_frag = 0;
+
+	bool timing = false;
+	std::vector<hipEvent_t> ev;     // groups of 4: start, after fused, after gate, after bank
+	uint32_t timed_calls = 0;
+};
+
+static void mat4_mul (const double* a, const double* b, double* c)
+{
+	double t[16];
+	for (int i = 0; i < 4; ++i)
+		for (int j = 0; j < 4; ++j) {
+			double s = 0;
+			for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+			t[i * 4 + j] = s;
+		}
+	memcpy (c, t, sizeof (t));
+}
+
+static int upload_consts (mtr_engine* e)
+{
+	// (A^K)^(2^d), d = 0..5, in double, rounded once to float
+	double A[16], B[4], P[16];
+	mtr_setup_kweight_matrix (e->kw, A, B);
+	for (int i = 0; i < 16; ++i) P[i] = (i % 5 == 0) ? 1.0 : 0.0;
+	for (int i = 0; i < e->run; ++i) mat4_mul (A, P, P);
+	float m[6 * 16];
+	for (int d = 0; d < 6; ++d) {
+		for (int i = 0; i < 16; ++i) m[d * 16 + i] = (float) P[i];
+		mat4_mul (P, P, P);
+	}
+	if (e->scan_m.reserve (96)) return fail (MTR_ERR_NOMEM, "hipMalloc scan_m");
+	HIPCHK (hipMemcpy (e->scan_m.p, m, sizeof (m), hipMemcpyHostToDevice));
+
+	float bp[100];
+	mtr_setup_bin_power (bp);
+	if (e->bin_power.reserve (100)) return fail (MTR_ERR_NOMEM, "hipMalloc bin_power");
+	HIPCHK (hipMemcpy (e->bin_power.p, bp, sizeof (bp), hipMemcpyHostToDevice));
+
+	// 48-tap kernels of phases 1..3 from the 5x24 table (resampler.cc:216-227)
+	float tab[120], g[3][48];
+	mtr_setup_fir_table (tab);
+	for (int ph = 1; ph <= 3; ++ph)
+		for (int i = 0; i < 48; ++i)
+			g[ph - 1][i] = (i < 24) ? tab[24 * ph + i] : tab[24 * (4 - ph) + (47 - i)];
+	if (mtr_fused_upload_taps (&g[0][0])) return fail (MTR_ERR_HIP, "hipMemcpyToSymbol c_fir");
+	return MTR_OK;
+}
+
+static int state_init (mtr_engine* e, int what, hipStream_t st)
+{
+	if (mtr_launch_state_init (e->state.p, e->hist.p, e->cfg.n_streams, what, st)) return fail (MTR_ERR_HIP, "k_state_init");
+	return MTR_OK;
+}
+
+extern "C" {
+
+const char* mtr_last_error (void) { return g_err.c_str (); }
+const char* mtr_version (void) { return "meters.lv2_amd 0.1 (gfx950)"; }
+int mtr_abi_version (void) { return MTR_ABI_VERSION; }
+
+int mtr_kweight_coef (float sample_rate, float* out7)
+{
+	if (!out7 || !(sample_rate > 0)) return fail (MTR_ERR_ARG, "mtr_kweight_coef");
+	mtr_setup_kweight (sample_rate, out7);
+	return MTR_OK;
+}
+
+int mtr_fir_table (float* out120)
+{
+	if (!out120) return fail (MTR_ERR_ARG, "mtr_fir_table");
+	mtr_setup_fir_table (out120);
+	return MTR_OK;
+}
+
+int mtr_band_coef (double rate, uint32_t band, double* out36)
+{
+	if (!out36 || band >= MTR_NBANDS || !(rate > 0)) return fail (MTR_ERR_ARG, "mtr_band_coef");
+	mtr_setup_band (rate, band, out36);
+	return MTR_OK;
+}
+
+void mtr_hist_loudness (const int32_t* hm, const int32_t* hs, float* integ, float* integ_thr,
+                        float* rmin, float* rmax, float* rthr)
+{
+	float d[5];
+	mtr_setup_hist_loudness (hm, hs, &d[0], &d[1], &d[2], &d[3], &d[4]);
+	if (integ) *integ = d[0];
+	if (integ_thr) *integ_thr = d[1];
+	if (rmin) *rmin = d[2];
+	if (rmax) *rmax = d[3];
+	if (rthr) *rthr = d[4];
+}
+
+int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
+{
+	if (!cfg || !out || cfg->struct_size != sizeof (mtr_config)) return fail (MTR_ERR_ARG, "mtr_engine_create: bad config");
+	*out = nullptr;
+	if (cfg->n_streams == 0 || !(cfg->sample_rate >= 8000.f) || cfg->meters == 0) return fail (MTR_ERR_ARG, "mtr_engine_create: n_streams / sample_rate / meters");
+	if (cfg->n_channels != 1 && cfg->n_channels != 2) return fail (MTR_ERR_ARG, "n_channels must be 1 or 2");
+	if (cfg->n_channels == 1 && (cfg->meters & (MTR_METER_EBU | MTR_METER_TRUEPEAK)))
+		return fail (MTR_ERR_UNSUPPORTED, "EBU / TRUEPEAK need stereo frames (the reference's EBUr128 plugin is stereo only)");
+	if (cfg->meters & (MTR_METER_TPBALLIST | MTR_METER_BITSTATS | MTR_METER_SIGDIST))
+		return fail (MTR_ERR_UNSUPPORTED, "TPBALLIST / BITSTATS / SIGDIST are not built yet (SURVEY.md §8f)");
+	if (cfg->tune_run != 0 && cfg->tune_run != 13 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 13 or 39");
+
+	int ndev = 0;
+	if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0)
+		return fail (MTR_ERR_NODEVICE, "no HIP device: the engine has no CPU path");
+	if (cfg->device < 0 || cfg->device >= ndev) return fail (MTR_ERR_ARG, "device ordinal out of range");
+	HIPCHK (hipSetDevice (cfg->device));
+
+	mtr_engine* e = new (std::nothrow) mtr_engine ();
+	if (!e) return fail (MTR_ERR_NOMEM, "new mtr_engine");
+	e->cfg = *cfg;
+	e->run = cfg->tune_run ? (int) cfg->tune_run : 13;
+	e->fragm = (uint32_t) ((int) cfg->sample_rate / 20);     // ebu_r128_proc.cc:170
+	e->frcnt = e->fragm;
+	mtr_setup_kweight (cfg->sample_rate, e->kw);
+	e->omega = 1.0f - expf (-2.0 * M_PI * 1.0 / (double) cfg->sample_rate);   // spectrumlv2.c:98
+
+	const uint32_t S = cfg->n_streams;
+	int rc = MTR_OK;
+	if (e->state.reserve (S) || e->hist.reserve ((size_t) S * 2 * MTR_HIST_LEN)
+	    || e->fir_hist[0].reserve ((size_t) S * MTR_FIR_HALO * 2) || e->fir_hist[1].reserve ((size_t) S * MTR_FIR_HALO * 2))
+		rc = fail (MTR_ERR_NOMEM, "hipMalloc stream state");
+	if (rc == MTR_OK) rc = upload_consts (e);
+	if (rc == MTR_OK && (cfg->meters & MTR_METER_SPECTR30)) {
+		std::vector<double> c (MTR_NBANDS * 6 * 5);
+		for (uint32_t b = 0; b < MTR_NBANDS; ++b) {
+			double w[36];
+			mtr_setup_band ((double) cfg->sample_rate, b, w);
+			for (int i = 0; i < 6; ++i) {
+				double* o = &c[(b * 6 + i) * 5];
+				o[0] = w[i * 6 + 3]; o[1] = w[i * 6 + 4]; o[2] = w[i * 6 + 5];   // b0 b1 b2
+				o[3] = w[i * 6 + 1]; o[4] = w[i * 6 + 2];                         // a1 a2
+			}
+		}
+		if (e->bank_coef.reserve (c.size ()) || e->bank_z.reserve ((size_t) S * MTR_NBANDS * 12)
+		    || e->bank_val.reserve ((size_t) S * MTR_NBANDS) || e->bank_max.reserve ((size_t) S * MTR_NBANDS)
+		    || e->bank_ac.reserve (S))
+			rc = fail (MTR_ERR_NOMEM, "hipMalloc bank state");
+		else if (hipMemcpy (e->bank_coef.p, c.data (), c.size () * sizeof (double), hipMemcpyHostToDevice) != hipSuccess)
+			rc = fail (MTR_ERR_HIP, "hipMemcpy bank_coef");
+	}
+	if (rc != MTR_OK) { mtr_engine_destroy (e); return rc; }
+	*out = e;
+	return mtr_engine_reset (e);
+}
+
+void mtr_engine_destroy (mtr_engine* e)
+{
+	if (!e) return;
+	(void) hipSetDevice (e->cfg.device);
+	(void) hipDeviceSynchronize ();
+	for (hipEvent_t ev : e->ev) (void) hipEventDestroy (ev);
+	e->state.release (); e->hist.release (); e->fir_hist[0].release (); e->fir_hist[1].release ();
+	e->scan_m.release (); e->bin_power.release (); e->tile_power.release (); e->frag_power.release ();
+	e->stage.release (); e->tile_start.release (); e->seg_tile.release (); e->frag_tile.release ();
+	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
+	delete e;
+}
+
+int mtr_engine_reset (mtr_engine* e)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	hipStream_t st = e->last_stream;
+	int rc = state_init (e, MTR_INIT_ALL, st);
+	if (rc) return rc;
+	const size_t hb = (size_t) e->cfg.n_streams * MTR_FIR_HALO * 2 * sizeof (float);
+	HIPCHK (hipMemsetAsync (e->fir_hist[0].p, 0, hb, st));
+	HIPCHK (hipMemsetAsync (e->fir_hist[1].p, 0, hb, st));
+	if (e->cfg.meters & MTR_METER_SPECTR30) {
+		HIPCHK (hipMemsetAsync (e->bank_z.p, 0, e->bank_z.n * sizeof (double), st));
+		HIPCHK (hipMemsetAsync (e->bank_val.p, 0, e->bank_val.n * sizeof (float), st));
+		HIPCHK (hipMemsetAsync (e->bank_max.p, 0, e->bank_max.n * sizeof (float), st));
+		HIPCHK (hipMemsetAsync (e->bank_ac.p, 0, e->bank_ac.n * sizeof (int32_t), st));
+	}
+	e->frcnt = e->fragm;
+	e->integr = false;
+	e->hist_cur = 0;
+	e->last_n_frag = 0;
+	return MTR_OK;
+}
+
+int mtr_engine_integr_start (mtr_engine* e) { if (!e) return fail (MTR_ERR_ARG, "null engine"); e->integr = true;  return MTR_OK; }
+int mtr_engine_integr_pause (mtr_engine* e) { if (!e) return fail (MTR_ERR_ARG, "null engine"); e->integr = false; return MTR_OK; }
+int mtr_engine_integr_reset (mtr_engine* e)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	return state_init (e, MTR_INIT_INTEGR, e->last_stream);
+}
+int mtr_engine_truepeak_reset (mtr_engine* e)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	return state_init (e, MTR_INIT_TP, e->last_stream);
+}
+
+int mtr_engine_spectr_set_speed (mtr_engine* e, float v)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	if (v < 0.01) v = 0.01;                                    // spectrumlv2.c:172-175
+	if (v > 15.0) v = 15.0;
+	e->omega = 1.0f - expf (-2.0 * M_PI * v / (double) e->cfg.sample_rate);
+	return MTR_OK;
+}
+
+int mtr_engine_spectr_reset_peak (mtr_engine* e)
+{
+	if (!e || !(e->cfg.meters & MTR_METER_SPECTR30)) return fail (MTR_ERR_ARG, "no SPECTR30 in this engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	HIPCHK (hipMemsetAsync (e->bank_max.p, 0, e->bank_max.n * sizeof (float), e->last_stream));
+	return MTR_OK;
+}
+
+// Tiling plan for a call of n_frames starting with `frcnt` frames left in the open fragment.
+static int build_plan (mtr_engine* e, uint64_t N)
+{
+	Plan& pl = e->plan;
+	if (pl.valid && pl.n_frames == N && pl.frcnt_in == e->frcnt) return MTR_OK;
+	pl.valid = false;
+	const uint32_t LT = 64u * (uint32_t) e->run;
+	if (N >= 0xFFFFFFFFull) return fail (MTR_ERR_ARG, "n_frames per call must be < 2^32 - 1");
+
+	std::vector<uint32_t> ts, ft;
+	ts.reserve ((size_t) (N / LT + N / e->fragm + 4));
+	uint64_t pos = 0;
+	uint32_t left = e->frcnt;
+	ft.push_back (0);
+	while (pos < N) {
+		const uint32_t piece = (uint32_t) std::min<uint64_t> (std::min<uint64_t> (LT, left), N - pos);
+		ts.push_back ((uint32_t) pos);
+		pos += piece;
+		left -= piece;
+		if (left == 0) { ft.push_back ((uint32_t) ts.size ()); left = e->fragm; }
+	}
+	ts.push_back ((uint32_t) N);
+	const uint32_t n_tiles = (uint32_t) ts.size () - 1;
+	const uint32_t n_frag  = (uint32_t) ft.size () - 1;      // fragments that end inside this call
+	const uint32_t tail    = ft.back ();
+	ft.resize ((size_t) n_frag + 1);
+
+	// time segments: enough (stream, segment) waves to fill the chip; each at least 4 warm-up spans long
+	const uint32_t warm_tiles = (uint32_t) std::ceil (MTR_WARM_SEC * e->cfg.sample_rate / (float) LT);
+	const uint64_t min_seg_frames = (uint64_t) 4 * warm_tiles * LT;
+	uint32_t n_segs = e->cfg.tune_segments;
+	if (n_segs == 0) {
+		const uint32_t target_units = 8192;
+		n_segs = (target_units + e->cfg.n_streams - 1) / e->cfg.n_streams;
+	}
+	const uint64_t max_segs = std::max<uint64_t> (1, N / std::max<uint64_t> (min_seg_frames, 1));
+	n_segs = (uint32_t) std::min<uint64_t> (n_segs, max_segs);
+	n_segs = std::max<uint32_t> (1, std::min<uint32_t> (n_segs, n_tiles));
+	std::vector<uint32_t> sg (n_segs + 1);
+	for (uint32_t q = 0; q <= n_segs; ++q) sg[q] = (uint32_t) ((uint64_t) q * n_tiles / n_segs);
+	for (uint32_t q = 1; q < n_segs; ++q)
+		if ((uint64_t) ts[sg[q]] < (uint64_t) warm_tiles * LT) return fail (MTR_ERR_ARG, "internal: segment shorter than its warm-up");
+
+	if (e->tile_start.reserve (ts.size ()) || e->seg_tile.reserve (sg.size ()) || e->frag_tile.reserve (ft.size ())
+	    || e->tile_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_tiles, 1))
+	    || e->frag_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_frag, 1)))
+		return fail (MTR_ERR_NOMEM, "hipMalloc plan buffers");
+	// plain synchronous copies: the plan is rebuilt only when (n_frames, fragment phase) changes
+	HIPCHK (hipMemcpy (e->tile_start.p, ts.data (), ts.size () * 4, hipMemcpyHostToDevice));
+	HIPCHK (hipMemcpy (e->seg_tile.p, sg.data (), sg.size () * 4, hipMemcpyHostToDevice));
+	HIPCHK (hipMemcpy (e->frag_tile.p, ft.data (), ft.size () * 4, hipMemcpyHostToDevice));
+
+	pl.n_frames = N; pl.frcnt_in = e->frcnt; pl.frcnt_out = left;
+	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail;
+	pl.valid = true;
+	return MTR_OK;
+}
+
+static hipEvent_t next_event (mtr_engine* e, size_t idx)
+{
+	while (e->ev.size () <= idx) {
+		hipEvent_t v;
+		if (hipEventCreate (&v) != hipSuccess) return nullptr;
+		e->ev.push_back (v);
+	}
+	return e->ev[idx];
+}
+
+int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_frames,
+                               uint64_t stride, void* hip_stream)
+{
+	if (!e || !d_audio) return fail (MTR_ERR_ARG, "mtr_engine_process_device: null argument");
+	if (n_frames == 0) return MTR_OK;
+	if (stride < n_frames) return fail (MTR_ERR_ARG, "stream_stride_frames < n_frames");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	hipStream_t st = (hipStream_t) hip_stream;
+	e->last_stream = st;
+	const uint32_t S = e->cfg.n_streams;
+	const bool ebu = e->cfg.meters & MTR_METER_EBU, tp = e->cfg.meters & MTR_METER_TRUEPEAK;
+	const bool bank = e->cfg.meters & MTR_METER_SPECTR30;
+
+	const bool tm = e->timing && e->timed_calls < 4096;
+	const size_t ev0 = (size_t) e->timed_calls * 4;
+	if (tm) { hipEvent_t v = next_event (e, ev0); if (v) HIPCHK (hipEventRecord (v, st)); }
+
+	if (ebu || tp) {
+		int rc = build_plan (e, n_frames);
+		if (rc) return rc;
+		const Plan& pl = e->plan;
+		mtr_fused_args fa;
+		fa.audio = d_audio; fa.stride = stride;
+		fa.hist = e->fir_hist[e->hist_cur].p;
+		fa.tile_start = e->tile_start.p; fa.seg_tile = e->seg_tile.p; fa.scan_m = e->scan_m.p;
+		fa.state = e->state.p; fa.tile_power = e->tile_power.p;
+		fa.n_streams = S; fa.n_segs = pl.n_segs; fa.n_tiles = pl.n_tiles;
+		fa.warm_tiles = (uint32_t) std::ceil (MTR_WARM_SEC * e->cfg.sample_rate / (float) (64 * e->run));
+		fa.a0 = e->kw[0]; fa.a1 = e->kw[1]; fa.a2 = e->kw[2]; fa.b1 = e->kw[3]; fa.b2 = e->kw[4];
+		fa.c3 = e->kw[5]; fa.c4 = e->kw[6];
+		fa.gain_l = 1.0f; fa.gain_r = 1.0f;                  // _chan_gain[0..1], ebu_r128_proc.cc:29
+		if (mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st)) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());
+		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }
+
+		if (tp) {
+			if (mtr_launch_history (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p, e->fir_hist[e->hist_cur ^ 1].p, S, st))
+				return fail (MTR_ERR_HIP, "k_history launch");
+			e->hist_cur ^= 1;
+		}
+		mtr_gate_args ga;
+		ga.state = e->state.p; ga.hist = e->hist.p; ga.tile_power = e->tile_power.p;
+		ga.frag_tile = e->frag_tile.p; ga.frag_power = e->frag_power.p; ga.bin_power = e->bin_power.p;
+		ga.n_streams = S; ga.n_tiles = ebu ? pl.n_tiles : 0; ga.n_frag = ebu ? pl.n_frag : 0;
+		ga.tail_tile = ebu ? pl.tail_tile : 0;
+		ga.fragm = (float) e->fragm; ga.integr = e->integr ? 1 : 0;
+		if (mtr_launch_gate (ga, st)) return fail (MTR_ERR_HIP, "k_gate launch");
+		e->last_n_frag = ga.n_frag;
+		e->frcnt = pl.frcnt_out;
+	} else if (tm) {
+		hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st));
+	}
+	if (tm) { hipEvent_t v = next_event (e, ev0 + 2); if (v) HIPCHK (hipEventRecord (v, st)); }
+
+	if (bank) {
+		mtr_bank_args ba;
+		ba.audio = d_audio; ba.stride = stride; ba.n_frames = n_frames;
+		ba.coef = e->bank_coef.p; ba.z = e->bank_z.p; ba.val = e->bank_val.p; ba.mx = e->bank_max.p; ba.ac = e->bank_ac.p;
+		ba.n_streams = S; ba.n_channels = e->cfg.n_channels; ba.omega = e->omega;
+		if (mtr_launch_bank (ba, st)) return fail (MTR_ERR_HIP, "k_bank launch");
+	}
+	if (tm) {
+		hipEvent_t v = next_event (e, ev0 + 3); if (v) HIPCHK (hipEventRecord (v, st));
+		e->timed_calls++;
+	}
+	return MTR_OK;
+}
+
+int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_frames, uint64_t stride)
+{
+	if (!e || !h_audio) return fail (MTR_ERR_ARG, "mtr_engine_process_host: null argument");
+	if (n_frames == 0) return MTR_OK;
+	if (stride < n_frames) return fail (MTR_ERR_ARG, "stream_stride_frames < n_frames");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	const size_t C = e->cfg.n_channels;
+	const size_t total = (size_t) e->cfg.n_streams * n_frames * C;
+	if (e->stage.reserve (total)) return fail (MTR_ERR_NOMEM, "hipMalloc staging buffer");
+	hipStream_t st = e->last_stream;
+	// the staging buffer may still be read by the previous call
+	HIPCHK (hipStreamSynchronize (st));
+	HIPCHK (hipMemcpy2DAsync (e->stage.p, n_frames * C * sizeof (float), h_audio, stride * C * sizeof (float),
+	                          n_frames * C * sizeof (float), e->cfg.n_streams, hipMemcpyHostToDevice, st));
+	return mtr_engine_process_device (e, e->stage.p, n_frames, n_frames, st);
+}
+
+int mtr_engine_process_planar_host (mtr_engine* e, const float* const* ch, uint32_t n_frames)
+{
+	if (!e || !ch || !ch[0]) return fail (MTR_ERR_ARG, "mtr_engine_process_planar_host: null argument");
+	if (e->cfg.n_streams != 1) return fail (MTR_ERR_ARG, "planar host input is the n_streams == 1 (LV2) path");
+	if (n_frames == 0) return MTR_OK;
+	const uint32_t C = e->cfg.n_channels;
+	if (C == 2 && !ch[1]) return fail (MTR_ERR_ARG, "missing right channel");
+	std::vector<float> il ((size_t) n_frames * C);
+	if (C == 2) for (uint32_t i = 0; i < n_frames; ++i) { il[2 * i] = ch[0][i]; il[2 * i + 1] = ch[1][i]; }
+	else        memcpy (il.data (), ch[0], (size_t) n_frames * sizeof (float));
+	int rc = mtr_engine_process_host (e, il.data (), n_frames, n_frames);
+	if (rc) return rc;
+	// `il` dies with this frame: make sure the copy has been consumed
+	HIPCHK (hipStreamSynchronize (e->last_stream));
+	return MTR_OK;
+}
+
+int mtr_engine_sync (mtr_engine* e)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	HIPCHK (hipStreamSynchronize (e->last_stream));
+	return MTR_OK;
+}
+
+static int check_range (mtr_engine* e, uint32_t first, uint32_t count)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	if ((uint64_t) first + count > e->cfg.n_streams) return fail (MTR_ERR_ARG, "stream range out of bounds");
+	return MTR_OK;
+}
+
+int mtr_engine_results (mtr_engine* e, uint32_t first, uint32_t count, mtr_stream_result* out)
+{
+	int rc = check_range (e, first, count);
+	if (rc) return rc;
+	if (!out) return fail (MTR_ERR_ARG, "null output");
+	if (count == 0) return MTR_OK;
+	rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	std::vector<mtr_stream_state> h (count);
+	HIPCHK (hipMemcpy (h.data (), e->state.p + first, count * sizeof (mtr_stream_state), hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < count; ++i) {
+		const mtr_stream_state& s = h[i];
+		mtr_stream_result& r = out[i];
+		r.loudness_M = s.loud_M; r.maxloudn_M = s.max_M; r.loudness_S = s.loud_S; r.maxloudn_S = s.max_S;
+		r.integrated = s.integ; r.integ_thr = s.integ_thr;
+		r.range_min = s.rmin; r.range_max = s.rmax; r.range_thr = s.rthr;
+		r.hist_M_count = s.cnt_M; r.hist_S_count = s.cnt_S;
+		for (int c = 0; c < 2; ++c) {
+			r.truepeak[c] = s.tp_hold[c]; r.truepeak_call[c] = s.tp_last[c];
+			r.tpb_level[c] = s.tpb_m[c]; r.tpb_peak[c] = s.tpb_p[c];
+		}
+	}
+	return MTR_OK;
+}
+
+int mtr_engine_histograms (mtr_engine* e, uint32_t first, uint32_t count, int32_t* hm, int32_t* hs)
+{
+	int rc = check_range (e, first, count);
+	if (rc) return rc;
+	if (count == 0) return MTR_OK;
+	rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	std::vector<int32_t> h ((size_t) count * 2 * MTR_HIST_LEN);
+	HIPCHK (hipMemcpy (h.data (), e->hist.p + (size_t) first * 2 * MTR_HIST_LEN, h.size () * 4, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < count; ++i) {
+		if (hm) memcpy (hm + (size_t) i * MTR_HIST_LEN, &h[(size_t) i * 2 * MTR_HIST_LEN], MTR_HIST_LEN * 4);
+		if (hs) memcpy (hs + (size_t) i * MTR_HIST_LEN, &h[(size_t) i * 2 * MTR_HIST_LEN + MTR_HIST_LEN], MTR_HIST_LEN * 4);
+	}
+	return MTR_OK;
+}
+
+int mtr_engine_fragment_powers (mtr_engine* e, uint32_t first, uint32_t count, float* out,
+                                uint32_t cap, uint32_t* n_frag)
+{
+	int rc = check_range (e, first, count);
+	if (rc) return rc;
+	if (n_frag) *n_frag = e->last_n_frag;
+	if (!out || count == 0 || e->last_n_frag == 0) return MTR_OK;
+	if (cap < e->last_n_frag) return fail (MTR_ERR_ARG, "capacity_per_stream < n_frag");
+	rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	HIPCHK (hipMemcpy2D (out, (size_t) cap * 4, e->frag_power.p + (size_t) first * e->last_n_frag,
+	                     (size_t) e->last_n_frag * 4, (size_t) e->last_n_frag * 4, count, hipMemcpyDeviceToHost));
+	return MTR_OK;
+}
+
+int mtr_engine_spectrum (mtr_engine* e, uint32_t first, uint32_t count, float* val, float* mx, float* val_db, float* max_db)
+{
+	int rc = check_range (e, first, count);
+	if (rc) return rc;
+	if (!(e->cfg.meters & MTR_METER_SPECTR30)) return fail (MTR_ERR_ARG, "no SPECTR30 in this engine");
+	if (count == 0) return MTR_OK;
+	rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	const size_t n = (size_t) count * MTR_NBANDS;
+	std::vector<float> v (n), m (n);
+	HIPCHK (hipMemcpy (v.data (), e->bank_val.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
+	HIPCHK (hipMemcpy (m.data (), e->bank_max.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
+	for (size_t i = 0; i < n; ++i) {
+		// spectrumlv2.c:240-247.  The stored val carries the +1e-20f of :237; above the -100 dB floor
+		// (val > 5e-11) that addition does not change the float, so the port value is unaffected.
+		const float vs = sqrtf (2. * v[i]);
+		const float ms = sqrtf (2. * m[i]);
+		if (val) val[i] = v[i];
+		if (mx) mx[i] = m[i];
+		if (val_db) val_db[i] = vs > .00001f ? 20.0 * log10f (vs) : -100.0;
+		if (max_db) max_db[i] = ms > .00001f ? 20.0 * log10f (ms) : -100.0;
+	}
+	return MTR_OK;
+}
+
+int mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, void* hip_stream)
+{
+	if (!e || !d_hist || !d_max) return fail (MTR_ERR_ARG, "mtr_engine_aggregate_device: null argument");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, d_hist, d_max, hip_stream))
+		return fail (MTR_ERR_HIP, "k_aggregate launch");
+	return MTR_OK;
+}
+
+int mtr_engine_timing_enable (mtr_engine* e, int on)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	e->timing = on != 0;
+	e->timed_calls = 0;
+	return MTR_OK;
+}
+
+int mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, float* ms_bank, uint32_t* calls)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	int rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	float f = 0, g = 0, b = 0;
+	for (uint32_t i = 0; i < e->timed_calls; ++i) {
+		float t;
+		if (hipEventElapsedTime (&t, e->ev[i * 4], e->ev[i * 4 + 1]) == hipSuccess) f += t;
+		if (hipEventElapsedTime (&t, e->ev[i * 4 + 1], e->ev[i * 4 + 2]) == hipSuccess) g += t;
+		if (hipEventElapsedTime (&t, e->ev[i * 4 + 2], e->ev[i * 4 + 3]) == hipSuccess) b += t;
+	}
+	if (ms_fused) *ms_fused = f;
+	if (ms_gate) *ms_gate = g;
+	if (ms_bank) *ms_bank = b;
+	if (calls) *calls = e->timed_calls;
+	e->timed_calls = 0;
+	return MTR_OK;
+}
+
+int mtr_synth_fill_device (float* d_audio, uint32_t n_streams, uint64_t n_frames, uint64_t stride,
+                           uint32_t seed, float fs, int kind, void* hip_stream)
+{
+	if (!d_audio || stride < n_frames) return fail (MTR_ERR_ARG, "mtr_synth_fill_device");
+	if (n_frames == 0 || n_streams == 0) return MTR_OK;
+	if (mtr_launch_synth (d_audio, n_streams, n_frames, stride, seed, fs, kind, hip_stream)) return fail (MTR_ERR_HIP, "k_synth launch");
+	return MTR_OK;
+}
+
+} // extern "C"

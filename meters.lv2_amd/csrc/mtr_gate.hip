@@ -1,0 +1,277 @@
+// mtr_gate.hip — fragment bookkeeping, M/S loudness, histograms, gated integration and range.
+//
+// Replaces the once-per-fragment part of Ebu_r128_proc::process (ebumeter/ebu_r128_proc.cc:217-244),
+// addfrags (:251-260) and Ebu_r128_hist::addpoint / integrate / calc_integ / calc_range (:66-150).
+//
+// This TU is compiled with -ffp-contract=off and does its divisions / log10 in double rounded
+// back to float, so that given the same fragment powers every float it produces and every
+// histogram bin it increments is the one the reference produces on the host: floorf(10 v + 700.5f)
+// and floorf(100 log10f(s) + 0.5f) are bin decisions and must not see a fused multiply-add.
+//
+// One workgroup (256 lanes) per stream.  The reference does this work serially per fragment; here
+//   * fragment powers are summed per fragment from the tile powers of the fused kernel, in tile
+//     order, starting from the 1e-30f floor (or the carried partial sum),
+//   * each lane evaluates M (last 8 fragments) and S (last 60) for its own fragment with the same
+//     chronological summation order as addfrags(),
+//   * histogram inserts are integer atomics (order-independent, exact),
+//   * calc_integ / calc_range run once, at the last fragment whose `_div2` counter wraps inside
+//     this call — only that evaluation survives in the reference — serially on one lane so the
+//     float accumulation order of integrate() is the reference's.
+#include <hip/hip_runtime.h>
+
+#include "mtr_internal.h"
+
+#define CHUNK 256
+
+__device__ __forceinline__ float log10f_cr (float x) { return (float) log10 ((double) x); }
+__device__ __forceinline__ float divf_cr (float a, float b) { return (float) ((double) a / (double) b); }
+
+// Ebu_r128_hist::integrate  ebu_r128_proc.cc:82-102
+__device__ float hist_integrate (const int32_t* h, const float* bin_power, int i)
+{
+	int   j = i % 100, n = 0;
+	float s = 0;
+	while (i <= 750) {
+		const int k = h[i++];
+		n += k;
+		s += (float) k * bin_power[j++];
+		if (j == 100) { j = 0; s = divf_cr (s, 10.0f); }
+	}
+	return divf_cr (s, (float) n);
+}
+
+__device__ void hist_calc_integ (const int32_t* h, int count, const float* bp, float* vi, float* th)
+{
+	if (count < 50) { *vi = -200.0f; return; }
+	float s = hist_integrate (h, bp, 0);
+	*th = 10 * log10f_cr (s) - 10.0f;
+	int k = (int) (floorf (100 * log10f_cr (s) + 0.5f)) + 600;
+	if (k < 0) k = 0;
+	s = hist_integrate (h, bp, k);
+	*vi = 10 * log10f_cr (s);
+}
+
+__device__ void hist_calc_range (const int32_t* h, int count, const float* bp, float* v0, float* v1, float* th)
+{
+	if (count < 20) { *v0 = -200.0f; *v1 = -200.0f; return; }
+	float s = hist_integrate (h, bp, 0);
+	*th = 10 * log10f_cr (s) - 20.0f;
+	// ebu_r128_proc.cc:141: the 0.5 here is a double
+	int k = (int) (floorf ((float) ((double) (100 * log10f_cr (s)) + 0.5))) + 500;
+	if (k < 0) k = 0;
+	int i, j, n = 0;
+	for (i = k; i <= 750; i++) n += h[i];
+	const float a = 0.10f * n;
+	const float b = 0.95f * n;
+	for (i = k, s = 0; s < a; i++) s += h[i];
+	for (j = 750, s = n; s > b; j--) s -= h[j];
+	*v0 = divf_cr ((float) (i - 701), 10.0f);
+	*v1 = divf_cr ((float) (j - 699), 10.0f);
+}
+
+// addfrags  ebu_r128_proc.cc:251-260 on a chronological array: pw[-(n-1) .. 0]
+__device__ __forceinline__ float addfrags (const float* newest, int nfrag)
+{
+	float s = 0;
+	for (int i = nfrag - 1; i >= 0; --i) s += newest[-i];
+	return -0.6976f + 10 * log10f_cr (divf_cr (s, (float) nfrag));
+}
+
+__device__ __forceinline__ void hist_add (int32_t* h, int32_t* count, int32_t* error, float v)
+{
+	int k = (int) floorf (10 * v + 700.5f);     // ebu_r128_proc.cc:70
+	if (k < 0) return;
+	if (k > 750) { k = 750; atomicAdd (error, 1); }
+	atomicAdd (&h[k], 1);
+	atomicAdd (count, 1);
+}
+
+__global__ __launch_bounds__ (256) void k_gate (const mtr_gate_args a)
+{
+#pragma clang fp contract(off)
+	__shared__ float   pw[64 + CHUNK];          // chronological fragment powers: 64 history + chunk
+	__shared__ int32_t sh_hist[2][MTR_HIST_LEN];
+	__shared__ float   sh_red[2][256];
+	__shared__ int32_t sh_cnt[4];               // cnt_M cnt_S err_M err_S
+
+	const uint32_t s = blockIdx.x;
+	const int tid = threadIdx.x;
+	mtr_stream_state* const st = a.state + s;
+	const float* const tp = a.tile_power + (size_t) s * a.n_tiles;
+	int32_t* const ghist = a.hist + (size_t) s * 2 * MTR_HIST_LEN;
+
+	for (int i = tid; i < 64; i += 256) pw[i] = st->ring[i];
+	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) (&sh_hist[0][0])[i] = ghist[i];
+	if (tid < 4) sh_cnt[tid] = (tid == 0) ? st->cnt_M : (tid == 1) ? st->cnt_S : (tid == 2) ? st->err_M : st->err_S;
+	const int   div1_0 = st->div1, div2_0 = st->div2;
+	const float frpwr0 = st->frpwr;
+	float max_M = st->max_M, max_S = st->max_S;
+	float last_M = st->loud_M, last_S = st->loud_S;
+	__syncthreads ();
+
+	// Index (within this call) of the last fragment at which _div2 wraps: calc_* run there.
+	// _div2 after fragment f (0-based) is (div2_0 + f + 1) mod 10.
+	int f_calc = -1;
+	if (a.integr && a.n_frag > 0) {
+		const int r = (div2_0 + (int) a.n_frag) % 10;      // value after the last fragment
+		const int f = (int) a.n_frag - 1 - r;
+		if (f >= 0) f_calc = f;
+	}
+
+	for (uint32_t base = 0; base < a.n_frag; base += CHUNK) {
+		const int nf = min ((int) (a.n_frag - base), CHUNK);
+		// fragment mean powers of this chunk
+		if (tid < nf) {
+			const uint32_t f = base + tid;
+			float acc = (f == 0) ? frpwr0 : 1e-30f;
+			for (uint32_t j = a.frag_tile[f]; j < a.frag_tile[f + 1]; ++j) acc += tp[j];
+			const float p = divf_cr (acc, a.fragm);
+			pw[64 + tid] = p;
+			if (a.frag_power) a.frag_power[(size_t) s * a.n_frag + f] = p;
+		}
+		__syncthreads ();
+
+		float lm = -200.0f, ls = -200.0f;
+		if (tid < nf) {
+			lm = addfrags (&pw[64 + tid], 8);
+			ls = addfrags (&pw[64 + tid], 60);
+			if (!isfinite (lm) || lm < -200.f) lm = -200.0f;
+			if (!isfinite (ls) || ls < -200.f) ls = -200.0f;
+		}
+		// histogram inserts up to and including f_calc go in now, the rest after calc_*
+		const int f_abs = (int) base + tid;
+		const bool addM = a.integr && tid < nf && ((div1_0 + f_abs + 1) % 2 == 0);
+		const bool addS = a.integr && tid < nf && ((div2_0 + f_abs + 1) % 10 == 0);
+		if (addM && f_abs <= f_calc) hist_add (sh_hist[0], &sh_cnt[0], &sh_cnt[2], lm);
+		if (addS && f_abs <= f_calc) hist_add (sh_hist[1], &sh_cnt[1], &sh_cnt[3], ls);
+		sh_red[0][tid] = lm;
+		sh_red[1][tid] = ls;
+		__syncthreads ();
+
+		if (f_calc >= (int) base && f_calc < (int) base + nf) {
+			if (tid == 0) {
+				hist_calc_integ (sh_hist[0], sh_cnt[0], a.bin_power, &st->integ, &st->integ_thr);
+			} else if (tid == 64) {
+				hist_calc_range (sh_hist[1], sh_cnt[1], a.bin_power, &st->rmin, &st->rmax, &st->rthr);
+			}
+		}
+		__syncthreads ();
+		if (addM && f_abs > f_calc) hist_add (sh_hist[0], &sh_cnt[0], &sh_cnt[2], lm);
+		if (addS && f_abs > f_calc) hist_add (sh_hist[1], &sh_cnt[1], &sh_cnt[3], ls);
+
+		if (tid == 0) {
+			for (int i = 0; i < nf; ++i) {           // max-hold (order-free) and the last value
+				max_M = sh_red[0][i] > max_M ? sh_red[0][i] : max_M;
+				max_S = sh_red[1][i] > max_S ? sh_red[1][i] : max_S;
+			}
+			last_M = sh_red[0][nf - 1];
+			last_S = sh_red[1][nf - 1];
+		}
+		__syncthreads ();
+		// slide the power window: keep the newest 64 as history for the next chunk
+		float keep = 0;
+		if (tid < 64) keep = pw[nf + tid];
+		__syncthreads ();
+		if (tid < 64) pw[tid] = keep;
+		__syncthreads ();
+	}
+
+	// tiles of the still-open fragment: partial power carried to the next call
+	if (tid == 0) {
+		float acc = (a.n_frag == 0) ? frpwr0 : 1e-30f;
+		for (uint32_t j = a.tail_tile; j < a.n_tiles; ++j) acc += tp[j];
+		st->frpwr = acc;
+		st->loud_M = last_M; st->loud_S = last_S;
+		st->max_M = max_M;   st->max_S = max_S;
+		st->div1 = a.integr ? (div1_0 + (int) a.n_frag) % 2 : div1_0;
+		st->div2 = a.integr ? (div2_0 + (int) a.n_frag) % 10 : div2_0;
+		st->cnt_M = sh_cnt[0]; st->cnt_S = sh_cnt[1]; st->err_M = sh_cnt[2]; st->err_S = sh_cnt[3];
+		// true-peak hold
+		const float cl = __uint_as_float (st->tp_call[0]), cr = __uint_as_float (st->tp_call[1]);
+		st->tp_last[0] = cl; st->tp_last[1] = cr;
+		if (cl > st->tp_hold[0]) st->tp_hold[0] = cl;
+		if (cr > st->tp_hold[1]) st->tp_hold[1] = cr;
+		st->tp_call[0] = 0; st->tp_call[1] = 0;
+	}
+	for (int i = tid; i < 64; i += 256) st->ring[i] = pw[i];
+	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) ghist[i] = (&sh_hist[0][0])[i];
+}
+
+int mtr_launch_gate (const mtr_gate_args& a, void* stream)
+{
+	hipLaunchKernelGGL (k_gate, dim3 (a.n_streams), dim3 (256), 0, (hipStream_t) stream, a);
+	return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+// ---- state initialisation --------------------------------------------------------------------
+
+__global__ void k_state_init (mtr_stream_state* st, int32_t* hist, uint32_t n_streams, int what)
+{
+	const uint32_t s = blockIdx.x;
+	if (s >= n_streams) return;
+	mtr_stream_state* p = st + s;
+	const int tid = threadIdx.x;
+	if (what == MTR_INIT_ALL || what == MTR_INIT_INTEGR) {
+		for (int i = tid; i < 2 * MTR_HIST_LEN; i += blockDim.x) hist[(size_t) s * 2 * MTR_HIST_LEN + i] = 0;
+	}
+	if (tid != 0) return;
+	if (what == MTR_INIT_ALL) {
+		// Ebu_r128_proc::reset  ebu_r128_proc.cc:176-189
+		for (int i = 0; i < 8; ++i) p->kz[i] = 0;
+		p->frpwr = 1e-30f;
+		for (int i = 0; i < 64; ++i) p->ring[i] = 0;
+		p->loud_M = p->loud_S = -200.0f;
+		for (int c = 0; c < 2; ++c) {
+			p->tp_call[c] = 0; p->tp_last[c] = 0; p->tp_hold[c] = 0;
+			p->tpb_z1[c] = p->tpb_z2[c] = p->tpb_m[c] = p->tpb_p[c] = 0;
+		}
+	}
+	if (what == MTR_INIT_ALL || what == MTR_INIT_INTEGR) {
+		// integr_reset  ebu_r128_proc.cc:192-204
+		p->max_M = p->max_S = -200.0f;
+		p->integ = p->integ_thr = -200.0f;
+		p->rmin = p->rmax = p->rthr = -200.0f;
+		p->div1 = p->div2 = 0;
+		p->cnt_M = p->cnt_S = p->err_M = p->err_S = 0;
+	}
+	if (what == MTR_INIT_TP) {
+		for (int c = 0; c < 2; ++c) { p->tp_call[c] = 0; p->tp_last[c] = 0; p->tp_hold[c] = 0; p->tpb_m[c] = p->tpb_p[c] = 0; }
+	}
+}
+
+int mtr_launch_state_init (mtr_stream_state* st, int32_t* hist, uint32_t n_streams, int what, void* stream)
+{
+	hipLaunchKernelGGL (k_state_init, dim3 (n_streams), dim3 (64), 0, (hipStream_t) stream, st, hist, n_streams, what);
+	return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+// ---- cross-stream aggregate (input of the multi-GPU all-reduce) ---------------------------------
+
+__global__ void k_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
+                             int32_t* d_hist, float* d_max)
+{
+	// one block per histogram bin group; grid-stride over streams
+	const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+	if (bin < 2 * MTR_HIST_LEN) {
+		int32_t acc = 0;
+		for (uint32_t s = 0; s < n_streams; ++s) acc += hist[(size_t) s * 2 * MTR_HIST_LEN + bin];
+		d_hist[bin] = acc;
+	}
+	if (blockIdx.x == 0 && threadIdx.x < 4) {
+		float m = (threadIdx.x < 2) ? 0.f : -200.f;
+		for (uint32_t s = 0; s < n_streams; ++s) {
+			const float v = threadIdx.x == 0 ? st[s].tp_hold[0] : threadIdx.x == 1 ? st[s].tp_hold[1]
+			              : threadIdx.x == 2 ? st[s].max_M : st[s].max_S;
+			m = v > m ? v : m;
+		}
+		d_max[threadIdx.x] = m;
+	}
+}
+
+int mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
+                          int32_t* d_hist, float* d_max, void* stream)
+{
+	hipLaunchKernelGGL (k_aggregate, dim3 ((2 * MTR_HIST_LEN + 255) / 256), dim3 (256), 0, (hipStream_t) stream,
+	                    st, hist, n_streams, d_hist, d_max);
+	return hipGetLastError () == hipSuccess ? 0 : -1;
+}

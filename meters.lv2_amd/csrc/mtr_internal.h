@@ -1,0 +1,105 @@
+/* mtr_internal.h — shared between the engine host code and the HIP kernel TUs. Not installed. */
+#ifndef MTR_INTERNAL_H
+#define MTR_INTERNAL_H
+
+#include <stdint.h>
+
+#include "mtr_engine.h"
+
+#define MTR_FIR_HALO   47          /* 2*hl - 1 frames of history the 48-tap window needs */
+#define MTR_WARM_SEC   0.2f        /* K-filter warm-up for mid-stream segments: |lambda|^(0.2 fs) ~ 1e-21 */
+
+typedef struct mtr_stream_state mtr_stream_state;
+typedef struct mtr_fused_args mtr_fused_args;
+typedef struct mtr_gate_args mtr_gate_args;
+typedef struct mtr_bank_args mtr_bank_args;
+
+/* Per-stream persistent state (device). */
+struct mtr_stream_state {
+	float    kz[8];            /* K-filter states z1..z4, channel-interleaved: z1L z1R z2L z2R ... */
+	float    frpwr;            /* partial power of the fragment in progress (Ebu_r128_proc::_frpwr) */
+	float    ring[64];         /* _power[], chronological: ring[63] is the newest fragment */
+	int32_t  div1, div2;
+	float    loud_M, max_M, loud_S, max_S;
+	float    integ, integ_thr, rmin, rmax, rthr;
+	int32_t  cnt_M, cnt_S, err_M, err_S;
+	uint32_t tp_call[2];       /* float bits, atomicMax target of the fused kernel; zero between calls */
+	float    tp_last[2];       /* peak of the most recent call (process_max + read) */
+	float    tp_hold[2];       /* max since reset */
+	float    tpb_z1[2], tpb_z2[2], tpb_m[2], tpb_p[2];   /* TPBALLIST */
+};
+
+/* Arguments of the fused K-weighting + true-peak kernel (by value in the kernarg segment). */
+struct mtr_fused_args {
+	const float*    audio;        /* [S][stride][2] */
+	uint64_t        stride;       /* frames */
+	const float*    hist;         /* [S][47][2]: the 47 frames before frame 0 of this call */
+	const uint32_t* tile_start;   /* [n_tiles + 1] frame offsets; tile j = [start[j], start[j+1]) */
+	const uint32_t* seg_tile;     /* [n_segs + 1] first tile of each time segment */
+	const float*    scan_m;       /* [6][16] (A^K)^(2^d), row-major, for the wave scan */
+	mtr_stream_state* state;      /* [S] */
+	float*          tile_power;   /* [S][n_tiles] channel-weighted sum of y^2 over the tile */
+	uint32_t        n_streams, n_segs, n_tiles, warm_tiles;
+	float           a0, a1, a2, b1, b2, c3, c4;
+	float           gain_l, gain_r;
+};
+
+struct mtr_gate_args {
+	mtr_stream_state* state;      /* [S] */
+	int32_t*        hist;         /* [S][2][751] */
+	const float*    tile_power;   /* [S][n_tiles] */
+	const uint32_t* frag_tile;    /* [n_frag + 1] first tile of each fragment that ENDS in this call */
+	float*          frag_power;   /* [S][n_frag] out (mean power per fragment), may be NULL */
+	const float*    bin_power;    /* [100] 10^(j/100) as powf gives it on the host */
+	uint32_t        n_streams, n_tiles, n_frag;
+	uint32_t        tail_tile;    /* first tile after the last complete fragment (tiles of the open fragment) */
+	float           fragm;        /* frames per fragment, as float */
+	int32_t         integr;       /* integration on? */
+};
+
+struct mtr_bank_args {
+	const float*    audio;
+	uint64_t        stride;
+	uint64_t        n_frames;
+	const double*   coef;         /* [30][6][5]: b0 b1 b2 a1 a2 per section */
+	double*         z;            /* [S][30][12] section states */
+	float*          val;          /* [S][30] */
+	float*          mx;           /* [S][30] */
+	int32_t*        ac;           /* [S] dither toggle parity (shared by the 30 bands of a stream) */
+	uint32_t        n_streams, n_channels;
+	float           omega;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* host-side setup math (mtr_setup.c, plain C, no FMA contraction) */
+void mtr_setup_kweight (float fsamp, float* out7);
+void mtr_setup_fir_table (float* out120);
+void mtr_setup_band (double rate, uint32_t band, double* out36);
+void mtr_setup_bin_power (float* out100);
+void mtr_setup_kweight_matrix (const float* k7, double* A16, double* B4);
+void mtr_setup_hist_loudness (const int32_t* hist_M, const int32_t* hist_S, float* integ, float* integ_thr,
+                              float* rmin, float* rmax, float* rthr);
+#ifdef __cplusplus
+}
+
+/* kernel launchers (one per HIP TU) */
+int  mtr_launch_fused (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream);
+int  mtr_fused_upload_taps (const float* g144);    /* [3][48] full 48-tap kernels of phases 1..3 */
+int  mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
+                         float* hist_out, uint32_t n_streams, void* stream);
+int  mtr_launch_gate (const mtr_gate_args& a, void* stream);
+int  mtr_launch_state_init (mtr_stream_state* st, int32_t* hist, uint32_t n_streams, int what, void* stream);
+int  mtr_launch_bank (const mtr_bank_args& a, void* stream);
+int  mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
+                           int32_t* d_hist, float* d_max, void* stream);
+int  mtr_launch_synth (float* d_audio, uint32_t n_streams, uint64_t n_frames, uint64_t stride,
+                       uint32_t seed, float fs, int kind, void* stream);
+#endif
+
+#define MTR_INIT_ALL     0
+#define MTR_INIT_INTEGR  1
+#define MTR_INIT_TP      2
+
+#endif

@@ -1,0 +1,231 @@
+"""ctypes binding of include/mtr_engine.h (libmtr_engine.so).
+
+Names follow the reference's classes: Engine.integr_start/.integr_pause/.integr_reset mirror
+Ebu_r128_proc (ebumeter/ebu_r128_proc.h:77-79), Engine.results() returns the getters of
+ebu_r128_proc.h:81-94 per stream, Engine.process() is the batched process()/process_max()/
+spectrum_run inner loop.  Device buffers are passed as raw pointers (torch tensors' data_ptr()).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+METER_EBU, METER_TRUEPEAK, METER_SPECTR30 = 0x01, 0x02, 0x04
+HIST_LEN, NBANDS = 751, 30
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "lib", "libmtr_engine.so")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("meters", C.c_uint32), ("n_streams", C.c_uint32),
+                ("n_channels", C.c_uint32), ("sample_rate", C.c_float), ("device", C.c_int32),
+                ("max_frames", C.c_uint32), ("tune_run", C.c_uint32), ("tune_segments", C.c_uint32),
+                ("reserved", C.c_uint32 * 3)]
+
+
+class StreamResult(C.Structure):
+    """mtr_stream_result: Ebu_r128_proc's getters in declaration order, then true peak."""
+    _fields_ = [("loudness_M", C.c_float), ("maxloudn_M", C.c_float), ("loudness_S", C.c_float),
+                ("maxloudn_S", C.c_float), ("integrated", C.c_float), ("integ_thr", C.c_float),
+                ("range_min", C.c_float), ("range_max", C.c_float), ("range_thr", C.c_float),
+                ("hist_M_count", C.c_int32), ("hist_S_count", C.c_int32),
+                ("truepeak", C.c_float * 2), ("truepeak_call", C.c_float * 2),
+                ("tpb_level", C.c_float * 2), ("tpb_peak", C.c_float * 2)]
+
+
+def _load():
+    if not os.path.exists(lib_path):
+        raise ImportError(
+            f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). meters.lv2_amd has no CPU or pure-Python fallback.")
+    L = C.CDLL(lib_path)
+    vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
+    L.mtr_last_error.restype = C.c_char_p
+    L.mtr_version.restype = C.c_char_p
+    L.mtr_engine_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+    L.mtr_engine_destroy.argtypes = [vp]
+    L.mtr_engine_destroy.restype = None
+    for n in ("reset", "integr_start", "integr_pause", "integr_reset", "truepeak_reset",
+              "spectr_reset_peak", "sync"):
+        getattr(L, "mtr_engine_" + n).argtypes = [vp]
+    L.mtr_engine_spectr_set_speed.argtypes = [vp, f32]
+    L.mtr_engine_process_device.argtypes = [vp, vp, u64, u64, vp]
+    L.mtr_engine_process_host.argtypes = [vp, vp, u64, u64]
+    L.mtr_engine_process_planar_host.argtypes = [vp, C.POINTER(vp), u32]
+    L.mtr_engine_results.argtypes = [vp, u32, u32, C.POINTER(StreamResult)]
+    L.mtr_engine_histograms.argtypes = [vp, u32, u32, vp, vp]
+    L.mtr_engine_fragment_powers.argtypes = [vp, u32, u32, vp, u32, C.POINTER(u32)]
+    L.mtr_engine_spectrum.argtypes = [vp, u32, u32, vp, vp, vp, vp]
+    L.mtr_engine_aggregate_device.argtypes = [vp, vp, vp, vp]
+    L.mtr_hist_loudness.argtypes = [vp, vp] + [C.POINTER(f32)] * 5
+    L.mtr_hist_loudness.restype = None
+    L.mtr_engine_timing_enable.argtypes = [vp, C.c_int]
+    L.mtr_engine_timing_query.argtypes = [vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(u32)]
+    L.mtr_kweight_coef.argtypes = [f32, vp]
+    L.mtr_fir_table.argtypes = [vp]
+    L.mtr_band_coef.argtypes = [C.c_double, u32, vp]
+    L.mtr_synth_fill_device.argtypes = [vp, u32, u64, u64, u32, f32, C.c_int, vp]
+    return L
+
+
+lib = _load()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise EngineError(f"{what} failed ({rc}): {lib.mtr_last_error().decode()}")
+
+
+def exported_symbols():
+    """Every function include/mtr_engine.h declares, parsed from the header itself."""
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "mtr_engine.h")
+    txt = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(mtr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def kweight_coef(fs):
+    out = np.zeros(7, np.float32)
+    _check(lib.mtr_kweight_coef(fs, out.ctypes.data), "mtr_kweight_coef")
+    return out
+
+
+def fir_table():
+    out = np.zeros(120, np.float32)
+    _check(lib.mtr_fir_table(out.ctypes.data), "mtr_fir_table")
+    return out
+
+
+def band_coef(rate, band):
+    out = np.zeros(36, np.float64)
+    _check(lib.mtr_band_coef(float(rate), band, out.ctypes.data), "mtr_band_coef")
+    return out.reshape(6, 6)
+
+
+def hist_loudness(hist_M, hist_S):
+    """(integrated, integ_thr, range_min, range_max, range_thr) of (summed) histograms."""
+    hm = np.ascontiguousarray(hist_M, np.int32)
+    hs = np.ascontiguousarray(hist_S, np.int32)
+    o = [C.c_float() for _ in range(5)]
+    lib.mtr_hist_loudness(hm.ctypes.data, hs.ctypes.data, *[C.byref(x) for x in o])
+    return tuple(x.value for x in o)
+
+
+def synth_fill_device(ptr, n_streams, n_frames, stride, seed, fs=48000.0, kind=1, stream=0):
+    _check(lib.mtr_synth_fill_device(ptr, n_streams, n_frames, stride, seed, fs, kind, stream),
+           "mtr_synth_fill_device")
+
+
+class Engine:
+    def __init__(self, n_streams, sample_rate=48000.0, meters=METER_EBU | METER_TRUEPEAK,
+                 n_channels=2, device=0, tune_run=0, tune_segments=0):
+        cfg = _Config(struct_size=C.sizeof(_Config), meters=meters, n_streams=n_streams,
+                      n_channels=n_channels, sample_rate=sample_rate, device=device,
+                      max_frames=0, tune_run=tune_run, tune_segments=tune_segments)
+        self._h = C.c_void_p()
+        self.n_streams, self.meters, self.sample_rate = n_streams, meters, sample_rate
+        _check(lib.mtr_engine_create(C.byref(cfg), C.byref(self._h)), "mtr_engine_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mtr_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def reset(self):
+        _check(lib.mtr_engine_reset(self._h), "reset")
+
+    def integr_start(self):
+        _check(lib.mtr_engine_integr_start(self._h), "integr_start")
+
+    def integr_pause(self):
+        _check(lib.mtr_engine_integr_pause(self._h), "integr_pause")
+
+    def integr_reset(self):
+        _check(lib.mtr_engine_integr_reset(self._h), "integr_reset")
+
+    def truepeak_reset(self):
+        _check(lib.mtr_engine_truepeak_reset(self._h), "truepeak_reset")
+
+    def spectr_set_speed(self, v):
+        _check(lib.mtr_engine_spectr_set_speed(self._h, v), "spectr_set_speed")
+
+    def spectr_reset_peak(self):
+        _check(lib.mtr_engine_spectr_reset_peak(self._h), "spectr_reset_peak")
+
+    def process_device(self, ptr, n_frames, stride=None, stream=0):
+        _check(lib.mtr_engine_process_device(self._h, ptr, n_frames, stride or n_frames, stream), "process_device")
+
+    def process(self, x):
+        """x: host float32 [S, T, 2] (or [S, T] mono)."""
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.shape[0] == self.n_streams
+        _check(lib.mtr_engine_process_host(self._h, x.ctypes.data, x.shape[1], x.shape[1]), "process_host")
+
+    def process_planar(self, chans):
+        arrs = [np.ascontiguousarray(c, np.float32) for c in chans]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        _check(lib.mtr_engine_process_planar_host(self._h, ptrs, arrs[0].size), "process_planar_host")
+
+    def sync(self):
+        _check(lib.mtr_engine_sync(self._h), "sync")
+
+    def results(self, first=0, count=None):
+        count = self.n_streams - first if count is None else count
+        out = (StreamResult * count)()
+        _check(lib.mtr_engine_results(self._h, first, count, out), "results")
+        return out
+
+    def out9(self, first=0, count=None):
+        """[count, 9] float32: M, maxM, S, maxS, I, I_thr, Rmin, Rmax, R_thr."""
+        r = self.results(first, count)
+        return np.array([[getattr(x, f[0]) for f in StreamResult._fields_[:9]] for x in r], np.float32)
+
+    def truepeak(self, first=0, count=None):
+        r = self.results(first, count)
+        return np.array([[x.truepeak[0], x.truepeak[1]] for x in r], np.float32)
+
+    def histograms(self, first=0, count=None):
+        count = self.n_streams - first if count is None else count
+        hm = np.zeros((count, HIST_LEN), np.int32)
+        hs = np.zeros((count, HIST_LEN), np.int32)
+        _check(lib.mtr_engine_histograms(self._h, first, count, hm.ctypes.data, hs.ctypes.data), "histograms")
+        return hm, hs
+
+    def fragment_powers(self, first=0, count=None):
+        count = self.n_streams - first if count is None else count
+        n = C.c_uint32()
+        _check(lib.mtr_engine_fragment_powers(self._h, first, count, None, 0, C.byref(n)), "fragment_powers")
+        out = np.zeros((count, max(n.value, 1)), np.float32)
+        _check(lib.mtr_engine_fragment_powers(self._h, first, count, out.ctypes.data, out.shape[1], C.byref(n)),
+               "fragment_powers")
+        return out[:, :n.value]
+
+    def spectrum(self, first=0, count=None):
+        count = self.n_streams - first if count is None else count
+        a = [np.zeros((count, NBANDS), np.float32) for _ in range(4)]
+        _check(lib.mtr_engine_spectrum(self._h, first, count, *[x.ctypes.data for x in a]), "spectrum")
+        return dict(val=a[0], max=a[1], val_db=a[2], max_db=a[3])
+
+    def aggregate_device(self, hist_ptr, max_ptr, stream=0):
+        _check(lib.mtr_engine_aggregate_device(self._h, hist_ptr, max_ptr, stream), "aggregate_device")
+
+    def timing_enable(self, on=True):
+        _check(lib.mtr_engine_timing_enable(self._h, int(on)), "timing_enable")
+
+    def timing_query(self):
+        f, g, b, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint32()
+        _check(lib.mtr_engine_timing_query(self._h, C.byref(f), C.byref(g), C.byref(b), C.byref(n)), "timing_query")
+        return dict(ms_fused=f.value, ms_gate=g.value, ms_bank=b.value, calls=n.value)
