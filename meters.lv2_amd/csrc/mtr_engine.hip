@@ -47,13 +47,14 @@ struct Plan {
 	uint64_t n_frames = 0;
 	uint32_t frcnt_in = 0;      // frames left in the open fragment when the call starts
 	uint32_t frcnt_out = 0;
-	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0;
+	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0, buf_slots = 0;
 	bool     valid = false;
 };
 
 struct mtr_engine {
 	mtr_config cfg;
-	int      run = 13;            // K: frames per lane run
+	int      run = 39;            // K: frames per lane run
+	int      layout = 2;          // 1 = wave per segment (mtr_fused.hip), 2 = wave-specialised (mtr_fused2.hip)
 	uint32_t fragm = 0;           // frames per 50 ms fragment
 	uint32_t frcnt = 0;           // frames remaining in the open fragment (all streams in lock step)
 	bool     integr = false;
@@ -70,6 +71,8 @@ struct mtr_engine {
 	DevBuf<double>   bank_coef, bank_z;
 	DevBuf<float>    bank_val, bank_max;
 	DevBuf<int32_t>  bank_ac;
+	DevBuf<int32_t>  agg_hist;
+	DevBuf<float>    agg_max;
 	Plan             plan;
 	uint32_t         last_n_frag = 0;
 
@@ -116,7 +119,7 @@ static int upload_consts (mtr_engine* e)
 	for (int ph = 1; ph <= 3; ++ph)
 		for (int i = 0; i < 48; ++i)
 			g[ph - 1][i] = (i < 24) ? tab[24 * ph + i] : tab[24 * (4 - ph) + (47 - i)];
-	if (mtr_fused_upload_taps (&g[0][0])) return fail (MTR_ERR_HIP, "hipMemcpyToSymbol c_fir");
+	if (mtr_fused_upload_taps (&g[0][0]) || mtr_fused2_upload_taps (&g[0][0])) return fail (MTR_ERR_HIP, "hipMemcpyToSymbol c_fir");
 	return MTR_OK;
 }
 
@@ -186,7 +189,11 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	mtr_engine* e = new (std::nothrow) mtr_engine ();
 	if (!e) return fail (MTR_ERR_NOMEM, "new mtr_engine");
 	e->cfg = *cfg;
-	e->run = cfg->tune_run ? (int) cfg->tune_run : 13;
+	// layout 2 (wave-specialised workgroups, 39-frame lane runs) is the default; layout 1 is the
+	// first design (one wave per stream segment), kept for comparison and for 13-frame runs
+	e->layout = cfg->tune_layout ? (int) cfg->tune_layout : (cfg->tune_run == 13 ? 1 : 2);
+	e->run = cfg->tune_run ? (int) cfg->tune_run : 39;
+	if (e->layout == 2 && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layout 2 needs tune_run 39"); }
 	e->fragm = (uint32_t) ((int) cfg->sample_rate / 20);     // ebu_r128_proc.cc:170
 	e->frcnt = e->fragm;
 	mtr_setup_kweight (cfg->sample_rate, e->kw);
@@ -231,6 +238,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->scan_m.release (); e->bin_power.release (); e->tile_power.release (); e->frag_power.release ();
 	e->stage.release (); e->tile_start.release (); e->seg_tile.release (); e->frag_tile.release ();
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
+	e->agg_hist.release (); e->agg_max.release ();
 	delete e;
 }
 
@@ -343,6 +351,9 @@ static int build_plan (mtr_engine* e, uint64_t N)
 
 	pl.n_frames = N; pl.frcnt_in = e->frcnt; pl.frcnt_out = left;
 	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail;
+	uint32_t maxlen = n_segs > 1 ? LT : 0;                      // warm-up tiles are full tiles
+	for (uint32_t j = 0; j < n_tiles; ++j) maxlen = std::max (maxlen, ts[j + 1] - ts[j]);
+	pl.buf_slots = (maxlen + 48 + 127) / 128 * 128;
 	pl.valid = true;
 	return MTR_OK;
 }
@@ -388,7 +399,11 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.a0 = e->kw[0]; fa.a1 = e->kw[1]; fa.a2 = e->kw[2]; fa.b1 = e->kw[3]; fa.b2 = e->kw[4];
 		fa.c3 = e->kw[5]; fa.c4 = e->kw[6];
 		fa.gain_l = 1.0f; fa.gain_r = 1.0f;                  // _chan_gain[0..1], ebu_r128_proc.cc:29
-		if (mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st)) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());
+		fa.n_frames = n_frames;
+		fa.buf_slots = pl.buf_slots;
+		const int lrc = e->layout == 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
+		                               : mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st);
+		if (lrc) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());
 		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 		if (tp) {
@@ -438,6 +453,9 @@ int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_fra
 	HIPCHK (hipStreamSynchronize (st));
 	HIPCHK (hipMemcpy2DAsync (e->stage.p, n_frames * C * sizeof (float), h_audio, stride * C * sizeof (float),
 	                          n_frames * C * sizeof (float), e->cfg.n_streams, hipMemcpyHostToDevice, st));
+	// The source is pageable caller memory and the copy is truly asynchronous: the caller may free
+	// or reuse it as soon as we return, so wait for the copy (not for the kernels) here.
+	HIPCHK (hipStreamSynchronize (st));
 	return mtr_engine_process_device (e, e->stage.p, n_frames, n_frames, st);
 }
 
@@ -558,7 +576,10 @@ int mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, v
 {
 	if (!e || !d_hist || !d_max) return fail (MTR_ERR_ARG, "mtr_engine_aggregate_device: null argument");
 	HIPCHK (hipSetDevice (e->cfg.device));
-	if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, d_hist, d_max, hip_stream))
+	const uint32_t np = mtr_aggregate_parts (e->cfg.n_streams);
+	if (e->agg_hist.reserve ((size_t) np * 2 * MTR_HIST_LEN) || e->agg_max.reserve ((size_t) np * 4))
+		return fail (MTR_ERR_NOMEM, "hipMalloc aggregate scratch");
+	if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, e->agg_hist.p, e->agg_max.p, d_hist, d_max, hip_stream))
 		return fail (MTR_ERR_HIP, "k_aggregate launch");
 	return MTR_OK;
 }

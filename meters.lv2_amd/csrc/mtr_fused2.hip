@@ -1,0 +1,309 @@
+// mtr_fused2.hip — fused K-weighting + 4x true-peak kernel, wave-specialised layout (gfx950).
+//
+// Replaces the same reference loops as mtr_fused.hip (Ebu_r128_proc::detect_process
+// ebumeter/ebu_r128_proc.cc:302-337; Resampler::process zita-resampler/resampler.cc:211-235 +
+// TruePeakdsp::process_max jmeters/truepeakdsp.cc:101-124), reading each stereo frame from HBM once.
+//
+// What the first layout (one wave = one stream segment, mtr_fused.hip) taught on MI355X
+// (profiles/r01_*): the kernel is fp32-VALU bound (v_pk_fma_f32 issues at the chip's peak rate,
+// ~32.5 T instr/s), the K-weighting scan is a fixed cost per tile, and a 39-frame lane run
+// (one tile = one 50 ms fragment) needs 20 KB of LDS per wave, which caps occupancy at 2 waves
+// per SIMD.  Here one WORKGROUP of four waves owns a (stream, time segment) and shares the tile:
+//
+//   wave 3  "loader + K-filter":  streams tile j+1 from HBM straight into the other LDS buffer with
+//           global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip, lane-linear destination which is
+//           exactly the frame order we want), then runs the K-weighting of tile j from LDS:
+//           per-lane run of K = 39 frames from zero state, 6-step wave scan with (A^K)^(2^d),
+//           second pass from the true state accumulating y^2, carry to the next tile in registers.
+//   waves 0..2 "FIR":  wave w computes the three non-trivial polyphase branches for the R = 13
+//           outputs [l*39 + 13w, l*39 + 13w + 13) of every lane run l: 13 x 3 x 2 accumulators in
+//           registers, the 13+47 window frames streamed through them once, taps in SGPRs
+//           (groups of 16 taps per branch so they fit the scalar file).
+//   One s_barrier per tile swaps the two LDS buffers.  LDS per workgroup = 2 x (tile + 48 frames)
+//   = 39 KB at 48 kHz -> 4 workgroups = 16 waves per CU, 4 per SIMD, at <= 128 VGPRs.
+//
+// Lane stride in LDS is K = 39 slots (odd) -> every ds_read_b64 is bank-conflict free.
+// The loader wave has ~30% less work than a FIR wave; that slack is what hides HBM latency.
+#include <hip/hip_runtime.h>
+
+#include "mtr_internal.h"
+
+typedef float v2f __attribute__ ((ext_vector_type (2)));
+
+__constant__ float c_fir2[3][48];   // 48-tap kernels of phases 1..3, index 0 = oldest window sample
+
+int mtr_fused2_upload_taps (const float* g144)
+{
+	return hipMemcpyToSymbol (HIP_SYMBOL (c_fir2), g144, sizeof (float) * 144) == hipSuccess ? 0 : -1;
+}
+
+__device__ __forceinline__ v2f shfl_up2 (v2f v, int d)
+{
+	return v2f{__shfl_up (v.x, d, 64), __shfl_up (v.y, d, 64)};
+}
+__device__ __forceinline__ v2f bcast2 (v2f v, int l)
+{
+	return v2f{__shfl (v.x, l, 64), __shfl (v.y, l, 64)};
+}
+__device__ __forceinline__ float wave_sum (float v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor (v, d, 64);
+	return v;
+}
+__device__ __forceinline__ float wave_max (float v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v = fmaxf (v, __shfl_xor (v, d, 64));
+	return v;
+}
+__device__ __forceinline__ v2f scrub (v2f v)
+{
+	return v2f{isfinite (v.x) ? v.x : 0.f, isfinite (v.y) ? v.y : 0.f};
+}
+
+// One K-weighting step for both channels (ebu_r128_proc.cc:321-326).  Same arithmetic as the
+// reference, associated so that the loop-carried chains are short: x depends on the previous x
+// through one FMA, y on the previous y through add + 2 FMA.
+#define KW_STEP(p, y)                                   \
+	{                                                   \
+		v2f t_ = (p) + 1e-15f;                          \
+		t_ = t_ - b2 * z2;                              \
+		const v2f x_ = t_ - b1 * z1;                    \
+		v2f u_ = a1 * z1;                               \
+		u_ = u_ + a2 * z2;                              \
+		u_ = u_ - c4 * z4;                              \
+		u_ = u_ - c3 * z3;                              \
+		y = a0 * x_ + u_;                               \
+		z2 = z1; z1 = x_; z4 += z3; z3 += y;            \
+	}
+
+template <int K, int R, bool EBU, bool TP>
+__global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args a)
+{
+	static_assert (K == 3 * R && (K & 1) == 1, "three FIR waves x R outputs per lane run; odd lane stride");
+	constexpr int TG = 16;                      // FIR taps per SGPR group
+	constexpr int LDR = TP ? 3 : 0;             // the loader / K-filter wave
+
+	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const int wid  = threadIdx.x >> 6;
+	const int NB   = (int) a.buf_slots;         // 8-byte slots per LDS buffer (even)
+	v2f* const buf0 = reinterpret_cast<v2f*> (smem);
+
+	const uint32_t unit = blockIdx.x;
+	const uint32_t s = unit / a.n_segs;
+	const uint32_t q = unit - s * a.n_segs;
+
+	const v2f* const src  = reinterpret_cast<const v2f*> (a.audio) + (size_t) s * a.stride;
+	const v2f* const hist = reinterpret_cast<const v2f*> (a.hist) + (size_t) s * MTR_FIR_HALO;
+	mtr_stream_state* const st = a.state + s;
+	const bool src_even = ((((size_t) s * a.stride) & 1) == 0) && ((reinterpret_cast<size_t> (a.audio) & 15) == 0);
+
+	const float a0 = a.a0, a1 = a.a1, a2 = a.a2, b1 = a.b1, b2 = a.b2, c3 = a.c3, c4 = a.c4;
+
+	const uint32_t jt0 = a.seg_tile[q], jt1 = a.seg_tile[q + 1];
+	const int64_t seg_start = a.tile_start[jt0];
+	const int nwarm = (EBU && q > 0) ? (int) a.warm_tiles : 0;
+	const int ntile = (int) (jt1 - jt0);
+	constexpr int LT = 64 * K;
+
+	// tile jj -> (first frame, length); warm-up tiles are full tiles before the segment
+	auto tile_of = [&] (int jj, int64_t& t0, int& len) {
+		if (jj < 0) { t0 = seg_start + (int64_t) jj * LT; len = LT; }
+		else        { t0 = a.tile_start[jt0 + jj]; len = (int) (a.tile_start[jt0 + jj + 1] - (uint32_t) t0); }
+	};
+
+	// Stage frames [t0 - 48, t0 + len) into `buf`: slot i <-> frame t0 - 48 + i (frame t0 at slot 48).
+	auto stage = [&] (int jj, v2f* buf) {
+		int64_t t0; int len;
+		tile_of (jj, t0, len);
+		const int nslot = len + 48;
+		// 16-byte pairs need an even first frame; the one tile that ends on an odd final frame of the
+		// call cannot fetch that frame as half of a pair without reading past the stream: plain path.
+		const bool tail_odd = (t0 + len == (int64_t) a.n_frames) && (a.n_frames & 1);
+		if (t0 >= 48 && src_even && ((t0 & 1) == 0) && !tail_odd) {
+			// LDS-DMA, 16 bytes (two frames) per lane per instruction, 1 KiB per wave-instruction.
+			// Source addresses past the end of the call are clamped (those slots are never consumed).
+			const int64_t fmax = (int64_t) a.n_frames - 2;
+			for (int i = 0; i < nslot; i += 128) {
+				int64_t f = t0 - 48 + i + 2 * lane;
+				f = f > fmax ? (fmax & ~(int64_t) 1) : f;
+				__builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void*) (src + f),
+				                                  (__attribute__ ((address_space (3))) void*) (buf + i), 16, 0, 0);
+			}
+		} else {
+			for (int i = lane; i < nslot; i += 64) {
+				const int64_t f = t0 - 48 + i;
+				v2f v = 0;
+				if (f >= 0) v = src[f < (int64_t) a.n_frames ? f : (int64_t) a.n_frames - 1];
+				else if (f >= -MTR_FIR_HALO) v = hist[MTR_FIR_HALO + f];
+				buf[i] = v;
+			}
+		}
+	};
+
+	// Workgroup barrier that is legal in wave-uniform divergent code: every wave of the block
+	// reaches exactly one of these per tile (the two role loops below have identical trip counts).
+	auto block_barrier = [] () {
+		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_barrier ();
+		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+	};
+
+	if (wid == LDR) {
+		// =================== loader + K-filter wave ===================
+		v2f k1 = 0, k2 = 0, k3 = 0, k4 = 0;        // carried K-filter state (wave-uniform)
+		if (EBU && q == 0) {
+			k1 = v2f{st->kz[0], st->kz[1]}; k2 = v2f{st->kz[2], st->kz[3]};
+			k3 = v2f{st->kz[4], st->kz[5]}; k4 = v2f{st->kz[6], st->kz[7]};
+		}
+		stage (-nwarm, buf0);
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+		block_barrier ();
+
+		for (int jj = -nwarm; jj < ntile; ++jj) {
+			const int par = (jj + nwarm) & 1;
+			v2f* const cur = buf0 + par * NB;
+			v2f* const nxt = buf0 + (par ^ 1) * NB;
+			int64_t t0; int len;
+			tile_of (jj, t0, len);
+			const bool warm = jj < 0;
+
+			if (jj + 1 < ntile) stage (jj + 1, nxt);          // in flight while this tile is filtered
+
+			if (EBU) {
+				const int run0 = lane * K;
+				const int rl = min (max (len - run0, 0), K);
+				const v2f* const xr = cur + 48 + run0;
+
+				// pass 1: this lane's run from zero state (lane 0 from the carried state)
+				v2f z1 = 0, z2 = 0, z3 = 0, z4 = 0;
+				if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
+				for (int n = 0; n < rl; ++n) { v2f y; KW_STEP (xr[n], y); (void) y; }
+
+				// wave scan (Hillis-Steele): v_l <- sum_{j<=l} (A^K)^(l-j) e_j.  A is block lower
+				// triangular (stage 1 does not see stage 2), so rows 0,1 only need columns 0,1.
+#pragma unroll
+				for (int d = 0; d < 6; ++d) {
+					const int off = 1 << d;
+					const float* M = a.scan_m + d * 16;
+					v2f w1 = shfl_up2 (z1, off), w2 = shfl_up2 (z2, off), w3 = shfl_up2 (z3, off), w4 = shfl_up2 (z4, off);
+					if (lane < off) { w1 = 0; w2 = 0; w3 = 0; w4 = 0; }
+					z1 += M[0] * w1;  z1 += M[1] * w2;
+					z2 += M[4] * w1;  z2 += M[5] * w2;
+					z3 += M[8] * w1;  z3 += M[9] * w2;  z3 += M[10] * w3; z3 += M[11] * w4;
+					z4 += M[12] * w1; z4 += M[13] * w2; z4 += M[14] * w3; z4 += M[15] * w4;
+				}
+
+				if (warm) {
+					k1 = bcast2 (z1, 63); k2 = bcast2 (z2, 63); k3 = bcast2 (z3, 63); k4 = bcast2 (z4, 63);
+				} else {
+					// pass 2: from the true start state (end state of the lane to the left), sum y^2
+					z1 = shfl_up2 (z1, 1); z2 = shfl_up2 (z2, 1); z3 = shfl_up2 (z3, 1); z4 = shfl_up2 (z4, 1);
+					if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
+					v2f sj = 0;
+					for (int n = 0; n < rl; ++n) { v2f y; KW_STEP (xr[n], y); sj += y * y; }
+					const float sl = wave_sum (sj.x), sr = wave_sum (sj.y);
+					if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = a.gain_l * sl + a.gain_r * sr;
+					const int last = (len - 1) / K;       // the lane holding the state after the last frame
+					k1 = bcast2 (z1, last); k2 = bcast2 (z2, last); k3 = bcast2 (z3, last); k4 = bcast2 (z4, last);
+				}
+				// ebu_r128_proc.cc:331-334: non-finite states are dropped at block ends
+				k1 = scrub (k1); k2 = scrub (k2); k3 = scrub (k3); k4 = scrub (k4);
+			}
+			asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // tile j+1 has landed in `nxt`
+			block_barrier ();
+		}
+		if (EBU && q == a.n_segs - 1 && lane == 0) {
+			st->kz[0] = k1.x; st->kz[1] = k1.y; st->kz[2] = k2.x; st->kz[3] = k2.y;
+			st->kz[4] = k3.x; st->kz[5] = k3.y; st->kz[6] = k4.x; st->kz[7] = k4.y;
+		}
+	} else if (TP) {
+		// =================== FIR wave `wid` ===================
+		// outputs m = lane*K + R*wid + r.  Window element j of output r is frame m - 47 + j,
+		// i.e. slot lane*K + R*wid + 1 + r + j (frame t0 sits at slot 48).
+		float pk_l = 0.f, pk_r = 0.f;
+		const int m0 = lane * K + R * wid;
+		block_barrier ();
+		for (int jj = -nwarm; jj < ntile; ++jj) {
+			if (jj >= 0) {
+				const int par = (jj + nwarm) & 1;
+				const v2f* const cur = buf0 + par * NB;
+				const int len = (int) (a.tile_start[jt0 + jj + 1] - a.tile_start[jt0 + jj]);
+				const int rlw = min (max (len - m0, 0), R);        // valid outputs of this lane's register tile
+				if (rlw > 0) {
+					const v2f* const xw = cur + m0 + 1;
+					v2f acc[R][3];
+#pragma unroll
+					for (int r = 0; r < R; ++r) { acc[r][0] = 0; acc[r][1] = 0; acc[r][2] = 0; }
+					// Taps go through SGPRs in groups of TG per branch: all 144 at once do not fit the
+					// scalar file (the compiler then parks them in VGPR lanes, one v_readlane per FMA).
+#pragma unroll 1
+					for (int g = 0; g < 48; g += TG) {
+						float t0_[TG], t1_[TG], t2_[TG];
+#pragma unroll
+						for (int k = 0; k < TG; ++k) { t0_[k] = c_fir2[0][g + k]; t1_[k] = c_fir2[1][g + k]; t2_[k] = c_fir2[2][g + k]; }
+						const v2f* const xg = xw + g;
+#pragma unroll
+						for (int j = 0; j < R + TG - 1; ++j) {
+							const v2f x = xg[j];
+#pragma unroll
+							for (int r = 0; r < R; ++r) {
+								const int k = j - r;
+								if (k >= 0 && k < TG) {
+									acc[r][0] += t0_[k] * x;
+									acc[r][1] += t1_[k] * x;
+									acc[r][2] += t2_[k] * x;
+								}
+							}
+						}
+					}
+#pragma unroll
+					for (int r = 0; r < R; ++r) {
+						const v2f x0 = xw[23 + r];              // phase 0 = identity: x[n - 24]
+						const bool ok = r < rlw;
+						const float ml = fmaxf (fmaxf (fabsf (acc[r][0].x), fabsf (acc[r][1].x)), fmaxf (fabsf (acc[r][2].x), fabsf (x0.x)));
+						const float mr = fmaxf (fmaxf (fabsf (acc[r][0].y), fabsf (acc[r][1].y)), fmaxf (fabsf (acc[r][2].y), fabsf (x0.y)));
+						pk_l = fmaxf (pk_l, ok ? ml : 0.f);
+						pk_r = fmaxf (pk_r, ok ? mr : 0.f);
+					}
+				}
+			}
+			block_barrier ();
+		}
+		pk_l = wave_max (pk_l);
+		pk_r = wave_max (pk_r);
+		if (lane == 0) {
+			atomicMax (&st->tp_call[0], __float_as_uint (pk_l));
+			atomicMax (&st->tp_call[1], __float_as_uint (pk_r));
+		}
+	}
+}
+
+template <int K, int R>
+static int launch2 (bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, hipStream_t st)
+{
+	const size_t lds = (size_t) 2 * a.buf_slots * sizeof (v2f);
+	const dim3 grid (n_units);
+	static bool raised = false;
+	if (!raised) {
+		const int mx = 160 * 1024;
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, true>,  hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		raised = true;
+	}
+	if (ebu && tp)  hipLaunchKernelGGL ((k_fused2<K, R, true, true>),  grid, dim3 (256), lds, st, a);
+	else if (ebu)   hipLaunchKernelGGL ((k_fused2<K, R, true, false>), grid, dim3 (64),  lds, st, a);
+	else            hipLaunchKernelGGL ((k_fused2<K, R, false, true>), grid, dim3 (256), lds, st, a);
+	return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+int mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream)
+{
+	switch (run) {
+	case 39: return launch2<39, 13> (ebu, tp, a, n_units, (hipStream_t) stream);
+	default: return -2;
+	}
+}

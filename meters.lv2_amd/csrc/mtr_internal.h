@@ -40,6 +40,8 @@ struct mtr_fused_args {
 	mtr_stream_state* state;      /* [S] */
 	float*          tile_power;   /* [S][n_tiles] channel-weighted sum of y^2 over the tile */
 	uint32_t        n_streams, n_segs, n_tiles, warm_tiles;
+	uint64_t        n_frames;     /* frames per stream in this call (bounds for staging) */
+	uint32_t        buf_slots;    /* wave-specialised kernel: 8-byte slots per LDS buffer (multiple of 128) */
 	float           a0, a1, a2, b1, b2, c3, c4;
 	float           gain_l, gain_r;
 };
@@ -86,14 +88,17 @@ void mtr_setup_hist_loudness (const int32_t* hist_M, const int32_t* hist_S, floa
 
 /* kernel launchers (one per HIP TU) */
 int  mtr_launch_fused (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream);
+int  mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream);
+int  mtr_fused2_upload_taps (const float* g144);
 int  mtr_fused_upload_taps (const float* g144);    /* [3][48] full 48-tap kernels of phases 1..3 */
 int  mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
                          float* hist_out, uint32_t n_streams, void* stream);
 int  mtr_launch_gate (const mtr_gate_args& a, void* stream);
 int  mtr_launch_state_init (mtr_stream_state* st, int32_t* hist, uint32_t n_streams, int what, void* stream);
 int  mtr_launch_bank (const mtr_bank_args& a, void* stream);
+uint32_t mtr_aggregate_parts (uint32_t n_streams);
 int  mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
-                           int32_t* d_hist, float* d_max, void* stream);
+                           int32_t* part_hist, float* part_max, int32_t* d_hist, float* d_max, void* stream);
 int  mtr_launch_synth (float* d_audio, uint32_t n_streams, uint64_t n_frames, uint64_t stride,
                        uint32_t seed, float fs, int kind, void* stream);
 #endif

@@ -26,7 +26,7 @@ class _Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("meters", C.c_uint32), ("n_streams", C.c_uint32),
                 ("n_channels", C.c_uint32), ("sample_rate", C.c_float), ("device", C.c_int32),
                 ("max_frames", C.c_uint32), ("tune_run", C.c_uint32), ("tune_segments", C.c_uint32),
-                ("reserved", C.c_uint32 * 3)]
+                ("tune_layout", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class StreamResult(C.Structure):
@@ -39,11 +39,29 @@ class StreamResult(C.Structure):
                 ("tpb_level", C.c_float * 2), ("tpb_peak", C.c_float * 2)]
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's); if our library pulled in the system copy first and torch then loaded
+    its own, the second runtime finds no GPU.  When torch is installed (it is only plumbing here:
+    device buffers, torch.distributed) load ITS copy first so both sides share it; without torch
+    the library's rpath (/opt/rocm/lib) applies."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def _load():
     if not os.path.exists(lib_path):
         raise ImportError(
             f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). meters.lv2_amd has no CPU or pure-Python fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(lib_path)
     vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
     L.mtr_last_error.restype = C.c_char_p
@@ -123,10 +141,11 @@ def synth_fill_device(ptr, n_streams, n_frames, stride, seed, fs=48000.0, kind=1
 
 class Engine:
     def __init__(self, n_streams, sample_rate=48000.0, meters=METER_EBU | METER_TRUEPEAK,
-                 n_channels=2, device=0, tune_run=0, tune_segments=0):
+                 n_channels=2, device=0, tune_run=0, tune_segments=0, tune_layout=0):
         cfg = _Config(struct_size=C.sizeof(_Config), meters=meters, n_streams=n_streams,
                       n_channels=n_channels, sample_rate=sample_rate, device=device,
-                      max_frames=0, tune_run=tune_run, tune_segments=tune_segments)
+                      max_frames=0, tune_run=tune_run, tune_segments=tune_segments,
+                      tune_layout=tune_layout)
         self._h = C.c_void_p()
         self.n_streams, self.meters, self.sample_rate = n_streams, meters, sample_rate
         _check(lib.mtr_engine_create(C.byref(cfg), C.byref(self._h)), "mtr_engine_create")
