@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--meters", default="ebu+tp", choices=["ebu+tp", "ebu", "tp", "ebu+tp+spectr30", "spectr30"])
     ap.add_argument("--run", type=int, default=0, help="frames per lane run (0 = engine default)")
     ap.add_argument("--segments", type=int, default=0)
+    ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 wave per segment, 2 wave-specialised")
+    ap.add_argument("--fir", type=int, default=0, help="0 auto (mirror-symmetric form), 1 dense 3x48 taps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -105,7 +107,8 @@ def main():
     agg_hist = torch.zeros(2 * 751, dtype=torch.int32, device=dev)
     agg_max = torch.zeros(4, dtype=torch.float32, device=dev)
 
-    eng = M.Engine(S, fs, meters, device=local, tune_run=args.run, tune_segments=args.segments)
+    eng = M.Engine(S, fs, meters, device=local, tune_run=args.run, tune_segments=args.segments,
+                   tune_layout=args.layout, tune_fir=args.fir)
     eng.integr_start()
 
     def step():

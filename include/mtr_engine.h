@@ -61,7 +61,8 @@ typedef struct {
 	uint32_t tune_run;       /* frames per lane run of the fused kernel: 0 = auto, else 13 or 39 */
 	uint32_t tune_segments;  /* time segments per stream per call: 0 = auto */
 	uint32_t tune_layout;    /* 0 = auto, 1 = one wave per stream segment, 2 = wave-specialised workgroups (run 39) */
-	uint32_t reserved[2];
+	uint32_t tune_fir;       /* interpolator form: 0 = auto (mirror-symmetric), 1 = dense 3 x 48 taps */
+	uint32_t reserved[1];
 } mtr_config;
 
 /* Per-stream results.  The first nine floats are Ebu_r128_proc's getters in

@@ -401,6 +401,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.gain_l = 1.0f; fa.gain_r = 1.0f;                  // _chan_gain[0..1], ebu_r128_proc.cc:29
 		fa.n_frames = n_frames;
 		fa.buf_slots = pl.buf_slots;
+		fa.fir_form = e->cfg.tune_fir;
 		const int lrc = e->layout == 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
 		                               : mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st);
 		if (lrc) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());

@@ -31,9 +31,17 @@
 typedef float v2f __attribute__ ((ext_vector_type (2)));
 
 __constant__ float c_fir2[3][48];   // 48-tap kernels of phases 1..3, index 0 = oldest window sample
+__constant__ float c_firs[3][24];   // mirror-symmetric form: P = (g1[i]+g1[47-i])/2, M = (g1[i]-g1[47-i])/2, Q = g2[i]
 
 int mtr_fused2_upload_taps (const float* g144)
 {
+	float pmq[3][24];
+	for (int i = 0; i < 24; ++i) {
+		pmq[0][i] = (float) (((double) g144[i] + (double) g144[47 - i]) * 0.5);
+		pmq[1][i] = (float) (((double) g144[i] - (double) g144[47 - i]) * 0.5);
+		pmq[2][i] = g144[48 + i];
+	}
+	if (hipMemcpyToSymbol (HIP_SYMBOL (c_firs), pmq, sizeof (pmq)) != hipSuccess) return -1;
 	return hipMemcpyToSymbol (HIP_SYMBOL (c_fir2), g144, sizeof (float) * 144) == hipSuccess ? 0 : -1;
 }
 
@@ -78,11 +86,101 @@ __device__ __forceinline__ v2f scrub (v2f v)
 		z2 = z1; z1 = x_; z4 += z3; z3 += y;            \
 	}
 
-template <int K, int R, bool EBU, bool TP>
+// ---- 4x interpolator, dense form: three 48-tap branches, R outputs per register tile ----------
+// xs points at the LDS slot of frame (m0 - 48), i.e. window element j of output r is xs[1 + r + j].
+// Taps go through SGPRs in groups of 16 per branch: all 144 at once do not fit the scalar file
+// (the compiler then parks them in VGPR lanes, one v_readlane per FMA).
+template <int R>
+__device__ __forceinline__ void fir_dense (const v2f* xs, int nvalid, float& pk_l, float& pk_r)
+{
+	constexpr int TG = 16;
+	const v2f* const xw = xs + 1;
+	v2f acc[R][3];
+#pragma unroll
+	for (int r = 0; r < R; ++r) { acc[r][0] = 0; acc[r][1] = 0; acc[r][2] = 0; }
+#pragma unroll 1
+	for (int g = 0; g < 48; g += TG) {
+		float t0_[TG], t1_[TG], t2_[TG];
+#pragma unroll
+		for (int k = 0; k < TG; ++k) { t0_[k] = c_fir2[0][g + k]; t1_[k] = c_fir2[1][g + k]; t2_[k] = c_fir2[2][g + k]; }
+		const v2f* const xg = xw + g;
+#pragma unroll
+		for (int j = 0; j < R + TG - 1; ++j) {
+			const v2f x = xg[j];
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				const int k = j - r;
+				if (k >= 0 && k < TG) {
+					acc[r][0] += t0_[k] * x;
+					acc[r][1] += t1_[k] * x;
+					acc[r][2] += t2_[k] * x;
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const v2f x0 = xw[23 + r];              // phase 0 = identity: x[n - 24]
+		const bool ok = r < nvalid;
+		const float ml = fmaxf (fmaxf (fabsf (acc[r][0].x), fabsf (acc[r][1].x)), fmaxf (fabsf (acc[r][2].x), fabsf (x0.x)));
+		const float mr = fmaxf (fmaxf (fabsf (acc[r][0].y), fabsf (acc[r][1].y)), fmaxf (fabsf (acc[r][2].y), fabsf (x0.y)));
+		pk_l = fmaxf (pk_l, ok ? ml : 0.f);
+		pk_r = fmaxf (pk_r, ok ? mr : 0.f);
+	}
+}
+
+// ---- 4x interpolator, mirror-symmetric form -------------------------------------------------------
+// The polyphase table is symmetric: branch 3 is branch 1 reversed (g3[i] = g1[47-i]) and branch 2 is
+// its own mirror.  With a_i = w[i], b_i = w[47-i] (i < 24), s_i = a_i + b_i, d_i = a_i - b_i:
+//     y1 = sum P_i s_i + sum M_i d_i,   y3 = sum P_i s_i - sum M_i d_i,   y2 = sum Q_i s_i
+// where P = (g1[i] + g1[47-i]) / 2, M = (g1[i] - g1[47-i]) / 2, Q = g2[i]:  2 adds + 3 FMAs per
+// (output, i) instead of 6 FMAs -> 120 instead of 144 packed operations per stereo frame.
+// For output r and i = G*g + k:  a = xs[1 + r + i],  b = xs[48 + r - i].
+template <int R>
+__device__ __forceinline__ void fir_sym (const v2f* xs, int nvalid, float& pk_l, float& pk_r)
+{
+	constexpr int G = 6;                         // mirror pairs per SGPR tap group
+	v2f aS[R], aD[R], aQ[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) { aS[r] = 0; aD[r] = 0; aQ[r] = 0; }
+#pragma unroll 1
+	for (int g = 0; g < 24; g += G) {
+		float tp[G], tm[G], tq[G];
+#pragma unroll
+		for (int k = 0; k < G; ++k) { tp[k] = c_firs[0][g + k]; tm[k] = c_firs[1][g + k]; tq[k] = c_firs[2][g + k]; }
+		const v2f* const xl = xs + 1 + g;        // a-side: xl[r + k]
+		const v2f* const xr = xs + 48 - g - (G - 1);   // b-side: xr[r + (G-1) - k]
+		v2f L[R + G - 1], B[R + G - 1];
+#pragma unroll
+		for (int j = 0; j < R + G - 1; ++j) { L[j] = xl[j]; B[j] = xr[j]; }
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+#pragma unroll
+			for (int k = 0; k < G; ++k) {
+				const v2f sv = L[r + k] + B[r + G - 1 - k];
+				const v2f dv = L[r + k] - B[r + G - 1 - k];
+				aS[r] += tp[k] * sv;
+				aD[r] += tm[k] * dv;
+				aQ[r] += tq[k] * sv;
+			}
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const v2f x0 = xs[24 + r];               // phase 0 = identity: x[n - 24]
+		const v2f y1 = aS[r] + aD[r], y3 = aS[r] - aD[r];
+		const bool ok = r < nvalid;
+		const float ml = fmaxf (fmaxf (fabsf (y1.x), fabsf (y3.x)), fmaxf (fabsf (aQ[r].x), fabsf (x0.x)));
+		const float mr = fmaxf (fmaxf (fabsf (y1.y), fabsf (y3.y)), fmaxf (fabsf (aQ[r].y), fabsf (x0.y)));
+		pk_l = fmaxf (pk_l, ok ? ml : 0.f);
+		pk_r = fmaxf (pk_r, ok ? mr : 0.f);
+	}
+}
+
+template <int K, int R, bool EBU, bool TP, bool SYM>
 __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args a)
 {
 	static_assert (K == 3 * R && (K & 1) == 1, "three FIR waves x R outputs per lane run; odd lane stride");
-	constexpr int TG = 16;                      // FIR taps per SGPR group
 	constexpr int LDR = TP ? 3 : 0;             // the loader / K-filter wave
 
 	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
@@ -233,40 +331,11 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 				const int len = (int) (a.tile_start[jt0 + jj + 1] - a.tile_start[jt0 + jj]);
 				const int rlw = min (max (len - m0, 0), R);        // valid outputs of this lane's register tile
 				if (rlw > 0) {
-					const v2f* const xw = cur + m0 + 1;
-					v2f acc[R][3];
-#pragma unroll
-					for (int r = 0; r < R; ++r) { acc[r][0] = 0; acc[r][1] = 0; acc[r][2] = 0; }
-					// Taps go through SGPRs in groups of TG per branch: all 144 at once do not fit the
-					// scalar file (the compiler then parks them in VGPR lanes, one v_readlane per FMA).
-#pragma unroll 1
-					for (int g = 0; g < 48; g += TG) {
-						float t0_[TG], t1_[TG], t2_[TG];
-#pragma unroll
-						for (int k = 0; k < TG; ++k) { t0_[k] = c_fir2[0][g + k]; t1_[k] = c_fir2[1][g + k]; t2_[k] = c_fir2[2][g + k]; }
-						const v2f* const xg = xw + g;
-#pragma unroll
-						for (int j = 0; j < R + TG - 1; ++j) {
-							const v2f x = xg[j];
-#pragma unroll
-							for (int r = 0; r < R; ++r) {
-								const int k = j - r;
-								if (k >= 0 && k < TG) {
-									acc[r][0] += t0_[k] * x;
-									acc[r][1] += t1_[k] * x;
-									acc[r][2] += t2_[k] * x;
-								}
-							}
-						}
-					}
-#pragma unroll
-					for (int r = 0; r < R; ++r) {
-						const v2f x0 = xw[23 + r];              // phase 0 = identity: x[n - 24]
-						const bool ok = r < rlw;
-						const float ml = fmaxf (fmaxf (fabsf (acc[r][0].x), fabsf (acc[r][1].x)), fmaxf (fabsf (acc[r][2].x), fabsf (x0.x)));
-						const float mr = fmaxf (fmaxf (fabsf (acc[r][0].y), fabsf (acc[r][1].y)), fmaxf (fabsf (acc[r][2].y), fabsf (x0.y)));
-						pk_l = fmaxf (pk_l, ok ? ml : 0.f);
-						pk_r = fmaxf (pk_r, ok ? mr : 0.f);
+					if (SYM) {
+						fir_sym<7> (cur + m0, min (rlw, 7), pk_l, pk_r);
+						if (rlw > 7) fir_sym<6> (cur + m0 + 7, rlw - 7, pk_l, pk_r);
+					} else {
+						fir_dense<R> (cur + m0, rlw, pk_l, pk_r);
 					}
 				}
 			}
@@ -281,7 +350,7 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 	}
 }
 
-template <int K, int R>
+template <int K, int R, bool SYM>
 static int launch2 (bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, hipStream_t st)
 {
 	const size_t lds = (size_t) 2 * a.buf_slots * sizeof (v2f);
@@ -289,21 +358,22 @@ static int launch2 (bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units
 	static bool raised = false;
 	if (!raised) {
 		const int mx = 160 * 1024;
-		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, true>,  hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, true, SYM>,  hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, false, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, false, true, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
 		raised = true;
 	}
-	if (ebu && tp)  hipLaunchKernelGGL ((k_fused2<K, R, true, true>),  grid, dim3 (256), lds, st, a);
-	else if (ebu)   hipLaunchKernelGGL ((k_fused2<K, R, true, false>), grid, dim3 (64),  lds, st, a);
-	else            hipLaunchKernelGGL ((k_fused2<K, R, false, true>), grid, dim3 (256), lds, st, a);
+	if (ebu && tp)  hipLaunchKernelGGL ((k_fused2<K, R, true, true, SYM>),  grid, dim3 (256), lds, st, a);
+	else if (ebu)   hipLaunchKernelGGL ((k_fused2<K, R, true, false, SYM>), grid, dim3 (64),  lds, st, a);
+	else            hipLaunchKernelGGL ((k_fused2<K, R, false, true, SYM>), grid, dim3 (256), lds, st, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
 int mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream)
 {
 	switch (run) {
-	case 39: return launch2<39, 13> (ebu, tp, a, n_units, (hipStream_t) stream);
+	case 39: return a.fir_form == 1 ? launch2<39, 13, false> (ebu, tp, a, n_units, (hipStream_t) stream)
+	                                : launch2<39, 13, true> (ebu, tp, a, n_units, (hipStream_t) stream);
 	default: return -2;
 	}
 }

@@ -26,7 +26,7 @@ class _Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("meters", C.c_uint32), ("n_streams", C.c_uint32),
                 ("n_channels", C.c_uint32), ("sample_rate", C.c_float), ("device", C.c_int32),
                 ("max_frames", C.c_uint32), ("tune_run", C.c_uint32), ("tune_segments", C.c_uint32),
-                ("tune_layout", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("tune_layout", C.c_uint32), ("tune_fir", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 class StreamResult(C.Structure):
@@ -141,11 +141,11 @@ def synth_fill_device(ptr, n_streams, n_frames, stride, seed, fs=48000.0, kind=1
 
 class Engine:
     def __init__(self, n_streams, sample_rate=48000.0, meters=METER_EBU | METER_TRUEPEAK,
-                 n_channels=2, device=0, tune_run=0, tune_segments=0, tune_layout=0):
+                 n_channels=2, device=0, tune_run=0, tune_segments=0, tune_layout=0, tune_fir=0):
         cfg = _Config(struct_size=C.sizeof(_Config), meters=meters, n_streams=n_streams,
                       n_channels=n_channels, sample_rate=sample_rate, device=device,
                       max_frames=0, tune_run=tune_run, tune_segments=tune_segments,
-                      tune_layout=tune_layout)
+                      tune_layout=tune_layout, tune_fir=tune_fir)
         self._h = C.c_void_p()
         self.n_streams, self.meters, self.sample_rate = n_streams, meters, sample_rate
         _check(lib.mtr_engine_create(C.byref(cfg), C.byref(self._h)), "mtr_engine_create")
