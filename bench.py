@@ -75,6 +75,7 @@ def main():
     import torch
     import torch.distributed as dist
     import meters.lv2_amd as M
+    from meters.lv2_amd import dist as mdist
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -103,7 +104,8 @@ def main():
     buf = torch.empty((S, T, 2), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     # synthetic programme-like signal, a different LCG seed per stream across the whole job
-    M.synth_fill_device(buf.data_ptr(), S, T, T, 777 + rank * S, fs, 1, stream)
+    first, _ = mdist.shard(S * world, world, rank)
+    M.synth_fill_device(buf.data_ptr(), S, T, T, 777 + first, fs, 1, stream)
     agg_hist = torch.zeros(2 * 751, dtype=torch.int32, device=dev)
     agg_max = torch.zeros(4, dtype=torch.float32, device=dev)
 
@@ -115,9 +117,7 @@ def main():
         eng.process_device(buf.data_ptr(), T, T, stream)
         if meters & (M.METER_EBU | M.METER_TRUEPEAK):
             eng.aggregate_device(agg_hist.data_ptr(), agg_max.data_ptr(), stream)
-            if world > 1:   # the final LUFS / peak reduction: the only collective of the job
-                dist.all_reduce(agg_hist, op=dist.ReduceOp.SUM)
-                dist.all_reduce(agg_max, op=dist.ReduceOp.MAX)
+            mdist.all_reduce_aggregate(agg_hist, agg_max)   # the only collective of the job (RCCL)
 
     for _ in range(args.warmup):
         step()
@@ -179,8 +179,9 @@ def main():
                         float(20 * np.log10(max(res.truepeak[0], res.truepeak[1], 1e-30))),
                         "job_max_truepeak": float(agg_max[:2].max().item())}
         if world == 1 and not args.no_cpu_baseline and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
-            n = min(S, 64)
+            n = min(S, 192)
             out["cpu_baseline"] = cpu_baseline(buf[:n].cpu().numpy(), fs)
+        out["programme"] = mdist.programme_summary(agg_hist, agg_max)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -1,0 +1,38 @@
+"""Multi-GPU host logic: static stream partition + the one collective of the job.
+
+Streams are independent, so rank r of W owns the block [first, first+count) and no audio ever
+crosses xGMI.  The only exchange is the final reduction of the per-rank aggregates that
+mtr_engine_aggregate_device() leaves in device memory: int32[2][751] loudness histograms (sum)
+and float[4] = {tp_L, tp_R, maxloudn_M, maxloudn_S} (max).  torch.distributed is plumbing here
+(backend "nccl" = RCCL on ROCm for device tensors; "gloo" works on CPU tensors, which is how the
+logic is tested without GPUs).
+"""
+from . import engine as _engine
+
+
+def shard(n_total, world_size, rank):
+    """Block partition: (first, count) of rank's streams; counts differ by at most one."""
+    base, extra = divmod(int(n_total), int(world_size))
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def all_reduce_aggregate(hist, maxv, group=None):
+    """In-place all-reduce of the aggregate tensors across ranks. Returns (hist, maxv)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(maxv, op=dist.ReduceOp.MAX, group=group)
+    return hist, maxv
+
+
+def programme_summary(hist, maxv):
+    """Programme-level record from the reduced aggregates: integrated loudness and range exactly as
+    Ebu_r128_hist::calc_integ / calc_range compute them from a histogram (ebu_r128_proc.cc:105-150)."""
+    h = hist.detach().cpu().numpy().reshape(2, _engine.HIST_LEN)
+    m = maxv.detach().cpu().numpy()
+    integ, integ_thr, rmin, rmax, rthr = _engine.hist_loudness(h[0], h[1])
+    return dict(integrated=integ, integ_thr=integ_thr, range_min=rmin, range_max=rmax, range_thr=rthr,
+                truepeak=(float(m[0]), float(m[1])), maxloudn_M=float(m[2]), maxloudn_S=float(m[3]),
+                hist_M_count=int(h[0].sum()), hist_S_count=int(h[1].sum()))

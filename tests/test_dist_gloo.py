@@ -1,0 +1,74 @@
+"""The N>1 host path on CPU: world_size-2 gloo processes shard the streams, build their per-rank
+aggregates (here from the oracle, standing in for mtr_engine_aggregate_device), all-reduce them
+with meters.lv2_amd.dist and must arrive at the single-process programme record."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _aggregate(streams):
+    """hist[2*751] int32 (sum) and max[4] float32 over a list of stream indices, via the oracle."""
+    sys.path[:0] = [ROOT, HERE]
+    import _signals as sig
+    from _oracle import Oracle
+    orc = Oracle()
+    hist = np.zeros((2, 751), np.int32)
+    mx = np.array([0, 0, -200, -200], np.float32)
+    for s in streams:
+        x = sig.g2(48000 * 8, 900 + s)
+        r = orc.ebu(x, 48000.0, 2400)
+        tp = orc.tp(x, 48000.0, 8192)
+        hist[0] += r["hist_M"]
+        hist[1] += r["hist_S"]
+        mx = np.maximum(mx, [tp[0], tp[1], r["out9"][1], r["out9"][3]]).astype(np.float32)
+    return hist.reshape(-1), mx
+
+
+def _worker(rank, world, port, n_total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path[:0] = [ROOT, HERE]
+    from meters.lv2_amd import dist as mdist
+    first, count = mdist.shard(n_total, world, rank)
+    h, m = _aggregate(range(first, first + count))
+    th, tm = torch.from_numpy(h.copy()), torch.from_numpy(m.copy())
+    mdist.all_reduce_aggregate(th, tm)
+    rec = mdist.programme_summary(th, tm)
+    if rank == 0:
+        torch.save(dict(rec=rec, hist=th, mx=tm, shard=(first, count)), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_partition():
+    from meters.lv2_amd import dist as mdist
+    for n, w in ((65536, 8), (10, 3), (7, 8), (1, 2)):
+        parts = [mdist.shard(n, w, r) for r in range(w)]
+        assert sum(c for _, c in parts) == n
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_reduce_equals_single_process(tmp_path):
+    from meters.lv2_amd import dist as mdist
+    n_total, world = 5, 2
+    out = str(tmp_path / "r0.pt")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, n_total, out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=False)
+    h, m = _aggregate(range(n_total))
+    assert np.array_equal(got["hist"].numpy(), h)
+    assert np.array_equal(got["mx"].numpy(), m)
+    want = mdist.programme_summary(torch.from_numpy(h), torch.from_numpy(m))
+    assert got["rec"] == want
+    assert got["shard"] == (0, 3)
+    assert -30 < want["integrated"] < 0 and want["hist_M_count"] == n_total * 80
