@@ -73,6 +73,8 @@ struct mtr_engine {
 	DevBuf<int32_t>  bank_ac;
 	DevBuf<int32_t>  agg_hist;
 	DevBuf<float>    agg_max;
+	DevBuf<float>    fir_g;         // [3][48] taps in device memory (ballistics kernel)
+	float            tpb_w[4];      // w1 w2 w3 g of TruePeakdsp::init
 	Plan             plan;
 	uint32_t         last_n_frag = 0;
 
@@ -120,6 +122,14 @@ static int upload_consts (mtr_engine* e)
 		for (int i = 0; i < 48; ++i)
 			g[ph - 1][i] = (i < 24) ? tab[24 * ph + i] : tab[24 * (4 - ph) + (47 - i)];
 	if (mtr_fused_upload_taps (&g[0][0]) || mtr_fused2_upload_taps (&g[0][0])) return fail (MTR_ERR_HIP, "hipMemcpyToSymbol c_fir");
+	if (e->fir_g.reserve (144)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_g");
+	HIPCHK (hipMemcpy (e->fir_g.p, g, sizeof (g), hipMemcpyHostToDevice));
+	// TruePeakdsp::init, jmeters/truepeakdsp.cc:154-157 — float / float / double, stored as float
+	const float fs = e->cfg.sample_rate;
+	e->tpb_w[0] = 4000.0f / fs / 4.0;
+	e->tpb_w[1] = 17200.0f / fs / 4.0;
+	e->tpb_w[2] = 1.0f - 7.0f / fs / 4.0;
+	e->tpb_w[3] = 0.502f;
 	return MTR_OK;
 }
 
@@ -176,8 +186,8 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	if (cfg->n_channels != 1 && cfg->n_channels != 2) return fail (MTR_ERR_ARG, "n_channels must be 1 or 2");
 	if (cfg->n_channels == 1 && (cfg->meters & (MTR_METER_EBU | MTR_METER_TRUEPEAK)))
 		return fail (MTR_ERR_UNSUPPORTED, "EBU / TRUEPEAK need stereo frames (the reference's EBUr128 plugin is stereo only)");
-	if (cfg->meters & (MTR_METER_TPBALLIST | MTR_METER_BITSTATS | MTR_METER_SIGDIST))
-		return fail (MTR_ERR_UNSUPPORTED, "TPBALLIST / BITSTATS / SIGDIST are not built yet (SURVEY.md §8f)");
+	if (cfg->meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST))
+		return fail (MTR_ERR_UNSUPPORTED, "BITSTATS / SIGDIST are not built yet (SURVEY.md §8f)");
 	if (cfg->tune_run != 0 && cfg->tune_run != 13 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 13 or 39");
 
 	int ndev = 0;
@@ -238,7 +248,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->scan_m.release (); e->bin_power.release (); e->tile_power.release (); e->frag_power.release ();
 	e->stage.release (); e->tile_start.release (); e->seg_tile.release (); e->frag_tile.release ();
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
-	e->agg_hist.release (); e->agg_max.release ();
+	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release ();
 	delete e;
 }
 
@@ -407,11 +417,6 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		if (lrc) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());
 		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }
 
-		if (tp) {
-			if (mtr_launch_history (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p, e->fir_hist[e->hist_cur ^ 1].p, S, st))
-				return fail (MTR_ERR_HIP, "k_history launch");
-			e->hist_cur ^= 1;
-		}
 		mtr_gate_args ga;
 		ga.state = e->state.p; ga.hist = e->hist.p; ga.tile_power = e->tile_power.p;
 		ga.frag_tile = e->frag_tile.p; ga.frag_power = e->frag_power.p; ga.bin_power = e->bin_power.p;
@@ -432,6 +437,23 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ba.coef = e->bank_coef.p; ba.z = e->bank_z.p; ba.val = e->bank_val.p; ba.mx = e->bank_max.p; ba.ac = e->bank_ac.p;
 		ba.n_streams = S; ba.n_channels = e->cfg.n_channels; ba.omega = e->omega;
 		if (mtr_launch_bank (ba, st)) return fail (MTR_ERR_HIP, "k_bank launch");
+	}
+	const bool tpb = e->cfg.meters & MTR_METER_TPBALLIST;
+	if (tpb) {
+		mtr_tpb_args ta;
+		ta.audio = d_audio; ta.stride = stride; ta.n_frames = n_frames;
+		ta.hist = e->fir_hist[e->hist_cur].p; ta.fir_g = e->fir_g.p; ta.state = e->state.p;
+		ta.n_streams = S; ta.n_channels = e->cfg.n_channels;
+		ta.w1 = e->tpb_w[0]; ta.w2 = e->tpb_w[1]; ta.w3 = e->tpb_w[2]; ta.g = e->tpb_w[3];
+		if (mtr_launch_tpb (ta, st)) return fail (MTR_ERR_HIP, "k_tpb launch");
+	}
+	if (tp || tpb) {
+		// the 47 frames before the next call; after every consumer of the current history
+		const int hrc = e->cfg.n_channels == 2
+			? mtr_launch_history (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p, e->fir_hist[e->hist_cur ^ 1].p, S, st)
+			: mtr_launch_history_mono (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p, e->fir_hist[e->hist_cur ^ 1].p, S, st);
+		if (hrc) return fail (MTR_ERR_HIP, "k_history launch");
+		e->hist_cur ^= 1;
 	}
 	if (tm) {
 		hipEvent_t v = next_event (e, ev0 + 3); if (v) HIPCHK (hipEventRecord (v, st));

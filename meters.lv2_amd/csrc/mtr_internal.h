@@ -73,6 +73,17 @@ struct mtr_bank_args {
 	float           omega;
 };
 
+typedef struct mtr_tpb_args mtr_tpb_args;
+struct mtr_tpb_args {
+	const float*    audio;        /* [S][stride][C] */
+	uint64_t        stride, n_frames;
+	const float*    hist;         /* [S][47][2] */
+	const float*    fir_g;        /* [3][48] */
+	mtr_stream_state* state;
+	uint32_t        n_streams, n_channels;
+	float           w1, w2, w3, g;   /* truepeakdsp.cc:154-157 */
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -97,6 +108,9 @@ int  mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames,
 int  mtr_launch_gate (const mtr_gate_args& a, void* stream);
 int  mtr_launch_state_init (mtr_stream_state* st, int32_t* hist, uint32_t n_streams, int what, void* stream);
 int  mtr_launch_bank (const mtr_bank_args& a, void* stream);
+int  mtr_launch_tpb (const mtr_tpb_args& a, void* stream);
+int  mtr_launch_history_mono (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
+                              float* hist_out, uint32_t n_streams, void* stream);
 uint32_t mtr_aggregate_parts (uint32_t n_streams);
 int  mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
                            int32_t* part_hist, float* part_max, int32_t* d_hist, float* d_max, void* stream);

@@ -11,7 +11,7 @@ import re
 
 import numpy as np
 
-METER_EBU, METER_TRUEPEAK, METER_SPECTR30 = 0x01, 0x02, 0x04
+METER_EBU, METER_TRUEPEAK, METER_SPECTR30, METER_TPBALLIST = 0x01, 0x02, 0x04, 0x08
 HIST_LEN, NBANDS = 751, 30
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -1,0 +1,158 @@
+"""A minimal LV2 host in ctypes for lib/meters_amd.so: descriptor enumeration, port wiring, a URID
+map, and just enough atom forging / parsing to drive the EBUr128 plugin headlessly.
+Layouts follow the public LV2 C ABI (include/lv2_min.h). Test infrastructure."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLUGIN_SO = os.path.join(ROOT, "meters.lv2_amd", "lib", "meters_amd.so")
+MTR_URI = "http://gareus.org/oss/lv2/meters#"
+ATOM = "http://lv2plug.in/ns/ext/atom#"
+
+
+class Feature(C.Structure):
+    _fields_ = [("URI", C.c_char_p), ("data", C.c_void_p)]
+
+
+class Descriptor(C.Structure):
+    pass
+
+
+_INST = C.CFUNCTYPE(C.c_void_p, C.POINTER(Descriptor), C.c_double, C.c_char_p, C.POINTER(C.POINTER(Feature)))
+_CONN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p)
+_VOIDH = C.CFUNCTYPE(None, C.c_void_p)
+_RUN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)
+_EXT = C.CFUNCTYPE(C.c_void_p, C.c_char_p)
+Descriptor._fields_ = [("URI", C.c_char_p), ("instantiate", _INST), ("connect_port", _CONN), ("activate", _VOIDH),
+                       ("run", _RUN), ("deactivate", _VOIDH), ("cleanup", _VOIDH), ("extension_data", _EXT)]
+
+_MAPFN = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.c_char_p)
+
+
+class UridMap(C.Structure):
+    _fields_ = [("handle", C.c_void_p), ("map", _MAPFN)]
+
+
+class Host:
+    def __init__(self):
+        from meters.lv2_amd import engine  # noqa: F401  (preloads the HIP runtime the way the engine wants it)
+        self.lib = C.CDLL(PLUGIN_SO)
+        self.lib.lv2_descriptor.restype = C.POINTER(Descriptor)
+        self.lib.lv2_descriptor.argtypes = [C.c_uint32]
+        self.urids = {}
+        self._mapfn = _MAPFN(self._map)
+        self.urid_map = UridMap(None, self._mapfn)
+
+    def _map(self, handle, uri):
+        u = uri.decode()
+        return self.urids.setdefault(u, len(self.urids) + 1)
+
+    def urid(self, uri):
+        return self.urids.setdefault(uri, len(self.urids) + 1)
+
+    def descriptors(self):
+        out, i = [], 0
+        while True:
+            d = self.lib.lv2_descriptor(i)
+            if not d:
+                return out
+            out.append(d.contents)
+            i += 1
+
+    def find(self, name):
+        for d in self.descriptors():
+            if d.URI.decode() == MTR_URI + name:
+                return d
+        raise KeyError(name)
+
+
+class Instance:
+    def __init__(self, host, name, rate=48000.0, with_urid_map=True):
+        self.host, self.desc = host, host.find(name)
+        feats = []
+        if with_urid_map:
+            self._f = Feature(b"http://lv2plug.in/ns/ext/urid#map", C.cast(C.pointer(host.urid_map), C.c_void_p))
+            feats.append(C.pointer(self._f))
+        arr = (C.POINTER(Feature) * (len(feats) + 1))(*feats, None)
+        self._arr = arr
+        self.handle = self.desc.instantiate(C.pointer(self.desc), rate, b"/tmp/", arr)
+        self.ports = {}
+
+    def ok(self):
+        return bool(self.handle)
+
+    def connect(self, port, array):
+        self.ports[port] = array
+        self.desc.connect_port(self.handle, port, array.ctypes.data_as(C.c_void_p))
+
+    def run(self, n):
+        self.desc.run(self.handle, n)
+
+    def cleanup(self):
+        if self.handle:
+            self.desc.cleanup(self.handle)
+            self.handle = None
+
+
+# ---- atoms ------------------------------------------------------------------------------------
+
+def _pad8(n):
+    return (n + 7) & ~7
+
+
+def forge_object(host, otype_uri, props):
+    """props: list of (key_uri, 'i'|'f', value). Returns bytes of a complete atom:Object."""
+    body = struct.pack("<II", 1, host.urid(otype_uri))
+    for key, kind, val in props:
+        t = host.urid(ATOM + ("Int" if kind == "i" else "Float"))
+        v = struct.pack("<i" if kind == "i" else "<f", val)
+        body += struct.pack("<IIII", host.urid(key), 0, 4, t) + v + b"\0" * 4
+    return struct.pack("<II", len(body), host.urid(ATOM + "Object")) + body
+
+
+def forge_sequence(host, objects):
+    """A control-port buffer: atom:Sequence of events at frame 0."""
+    body = struct.pack("<II", 0, 0)
+    for ob in objects:
+        ev = struct.pack("<q", 0) + ob
+        body += ev + b"\0" * (_pad8(len(ev)) - len(ev))
+    raw = struct.pack("<II", len(body), host.urid(ATOM + "Sequence")) + body
+    return np.frombuffer(raw + b"\0" * 64, np.uint8).copy()
+
+
+def notify_buffer(capacity=4096):
+    buf = np.zeros(capacity + 8, np.uint8)
+    return buf
+
+
+def arm_notify(buf):
+    """Hosts preset atom.size to the capacity before every run()."""
+    struct.pack_into("<II", buf, 0, buf.size - 8, 0)
+
+
+def parse_sequence(host, buf):
+    """-> list of (otype_uri, {key_uri: value}) for every object event in an atom:Sequence."""
+    rev = {v: k for k, v in host.urids.items()}
+    size, typ = struct.unpack_from("<II", buf, 0)
+    out, p, end = [], 16, 8 + size
+    raw = buf.tobytes()
+    while p + 16 <= end:
+        _frames, asize, atype = struct.unpack_from("<qII", raw, p)
+        if rev.get(atype, "").endswith(("#Object", "#Blank")):
+            _oid, otype = struct.unpack_from("<II", raw, p + 16)
+            q, qend, props = p + 24, p + 16 + asize, {}
+            while q + 16 <= qend:
+                key, _ctx, vsize, vtype = struct.unpack_from("<IIII", raw, q)
+                vt = rev.get(vtype, "")
+                if vt.endswith("#Float"):
+                    val = struct.unpack_from("<f", raw, q + 16)[0]
+                else:
+                    val = struct.unpack_from("<i", raw, q + 16)[0]
+                props[rev.get(key, key)] = val
+                q += _pad8(16 + vsize)
+            out.append((rev.get(otype, otype), props))
+        p += _pad8(16 + asize)
+    return out

@@ -340,3 +340,33 @@ def test_full_size_properties(M, oracle):
         e.process_device(small.data_ptr(), T)
         o9, tp = e.out9(), e.truepeak()
     assert np.allclose(o9[:, :4], c[0][pick, :4], atol=1e-4) and np.allclose(tp, c[1][pick], rtol=1e-6)
+
+
+def test_truepeak_ballistics_batch(M, oracle):
+    """TruePeakdsp::process (PPM-style ballistics) for a batch, two calls = two process()+read() blocks."""
+    S, T = 5, 6000
+    x = np.stack([sig.lcg_noise(T, 40 + s, 2.0 ** -(s % 3)) for s in range(S)])
+    with M.Engine(S, 48000.0, M.METER_TPBALLIST) as e:
+        got = []
+        for p in (0, 2500):
+            e.process(x[:, p:p + (2500 if p == 0 else 3500)])
+            r = e.results()
+            got.append([[(r[s].tpb_level[c], r[s].tpb_peak[c]) for c in range(2)] for s in range(S)])
+    for s in range(S):
+        for c in range(2):
+            ch = np.ascontiguousarray(x[s, :, c])
+            want = np.concatenate([oracle.tp_process_seq(ch[:2500], 48000.0, 2500),
+                                   ])
+            # a fresh oracle object per channel processed in the same two blocks
+            import ctypes as C
+            from _oracle import MoTp
+            t = MoTp()
+            oracle.lib.mo_tp_init(C.byref(t), 48000.0)
+            m, p = C.c_float(), C.c_float()
+            for i, (a, b) in enumerate(((0, 2500), (2500, 6000))):
+                seg = np.ascontiguousarray(ch[a:b])
+                oracle.lib.mo_tp_process(C.byref(t), seg, seg.size)
+                oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
+                assert abs(got[i][s][c][0] - m.value) < 2e-6 * max(1.0, m.value), (s, c, i)
+                assert abs(got[i][s][c][1] - p.value) < 2e-6 * max(1.0, p.value), (s, c, i)
+            assert want.shape == (1, 2)
