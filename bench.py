@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=8192, help="streams per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="audio seconds per stream per step")
-    ap.add_argument("--meters", default="ebu+tp", choices=["ebu+tp", "ebu", "tp", "ebu+tp+spectr30", "spectr30"])
+    ap.add_argument("--meters", default="ebu+tp", choices=["ebu+tp", "ebu", "tp", "ebu+tp+spectr30", "spectr30",
+                                                           "bitstats", "sigdist"])
     ap.add_argument("--run", type=int, default=0, help="frames per lane run (0 = engine default)")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 wave per segment, 2 wave-specialised")
@@ -95,7 +96,8 @@ def main():
     S, T = args.streams, int(round(args.seconds * fs))
     meters = {"ebu+tp": M.METER_EBU | M.METER_TRUEPEAK, "ebu": M.METER_EBU, "tp": M.METER_TRUEPEAK,
               "ebu+tp+spectr30": M.METER_EBU | M.METER_TRUEPEAK | M.METER_SPECTR30,
-              "spectr30": M.METER_SPECTR30}[args.meters]
+              "spectr30": M.METER_SPECTR30, "bitstats": M.METER_BITSTATS, "sigdist": M.METER_SIGDIST}[args.meters]
+    mono = bool(meters & (M.METER_BITSTATS | M.METER_SIGDIST))   # integer paths: the same buffer read as [S][2T] mono
 
     free, _ = torch.cuda.mem_get_info()
     need = S * T * 8
@@ -109,11 +111,14 @@ def main():
     agg_hist = torch.zeros(2 * 751, dtype=torch.int32, device=dev)
     agg_max = torch.zeros(4, dtype=torch.float32, device=dev)
 
-    eng = M.Engine(S, fs, meters, device=local, tune_run=args.run, tune_segments=args.segments,
-                   tune_layout=args.layout, tune_fir=args.fir)
+    eng = M.Engine(S, fs, meters, n_channels=1 if mono else 2, device=local, tune_run=args.run,
+                   tune_segments=args.segments, tune_layout=args.layout, tune_fir=args.fir)
     eng.integr_start()
 
     def step():
+        if mono:
+            eng.process_device(buf.data_ptr(), 2 * T, 2 * T, stream)
+            return
         eng.process_device(buf.data_ptr(), T, T, stream)
         if meters & (M.METER_EBU | M.METER_TRUEPEAK):
             eng.aggregate_device(agg_hist.data_ptr(), agg_max.data_ptr(), stream)
@@ -160,7 +165,7 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream": T, "sample_rate": fs,
                        "frames_per_s": frames_job / dt, "parallelism": f"streams sharded x{world}"},
         }
-        if tq["calls"] and tq["ms_fused"] > 0:
+        if tq["calls"] and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
             k_ms = tq["ms_fused"] / tq["calls"]
             achieved = S * T * BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -173,7 +178,13 @@ def main():
             k_ms = tq["ms_bank"] / tq["calls"]
             achieved = S * T * BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_bank", "kernel_ms": k_ms}
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": {"spectr30": "k_bank", "bitstats": "k_bitstats", "sigdist": "k_sigdist"}.get(args.meters, "k_bank"),
+                               "kernel_ms": k_ms}
+        if mono:
+            print(json.dumps(out), flush=True)
+            eng.close()
+            return
         res = eng.results(0, 1)[0]
         out["check"] = {"stream0_integrated_lufs": res.integrated, "stream0_dbtp":
                         float(20 * np.log10(max(res.truepeak[0], res.truepeak[1], 1e-30))),

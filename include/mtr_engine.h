@@ -134,6 +134,18 @@ int  mtr_engine_fragment_powers (mtr_engine* e, uint32_t first, uint32_t count, 
 int  mtr_engine_spectrum (mtr_engine* e, uint32_t first, uint32_t count,
                           float* val, float* max, float* val_db, float* max_db);
 
+/* Integer paths (mono engines, n_channels == 1, as the reference's bitmeter / SigDistHist plugins).
+ * replaces: float_stats' table and counters (src/bitmeter.c:63-105, layout src/uris.h:53-60):
+ *   hist [count][584], counters [count][5] = zero, pos, nan, inf, denormal, minmax [count][2] */
+int  mtr_engine_bitstats (mtr_engine* e, uint32_t first, uint32_t count,
+                          int32_t* hist, int32_t* counters, float* minmax);
+/* replaces: the state sdh_run's loop maintains (src/sigdistlv2.c:296-327): bins [count][361],
+ *   peak [count][2] = {count, bin}, moments [count][3] = {sum, mean, M2} (double), n [count] */
+int  mtr_engine_sigdist (mtr_engine* e, uint32_t first, uint32_t count,
+                         int32_t* bins, int32_t* peak, double* moments, int64_t* n);
+/* replaces: bim_reset (src/bitmeter.c:47-60) and the SDH reset */
+int  mtr_engine_intstat_reset (mtr_engine* e);
+
 /* ---- multi-GPU aggregate ---------------------------------------------------- */
 
 /* Sum the two loudness histograms over this engine's streams into d_hist[2][751] (int32) and take

@@ -73,6 +73,8 @@ struct mtr_engine {
 	DevBuf<int32_t>  bank_ac;
 	DevBuf<int32_t>  agg_hist;
 	DevBuf<float>    agg_max;
+	DevBuf<mtr_bitstats_state> bim;
+	DevBuf<mtr_sigdist_state>  sdh;
 	DevBuf<float>    fir_g;         // [3][48] taps in device memory (ballistics kernel)
 	float            tpb_w[4];      // w1 w2 w3 g of TruePeakdsp::init
 	Plan             plan;
@@ -186,8 +188,8 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	if (cfg->n_channels != 1 && cfg->n_channels != 2) return fail (MTR_ERR_ARG, "n_channels must be 1 or 2");
 	if (cfg->n_channels == 1 && (cfg->meters & (MTR_METER_EBU | MTR_METER_TRUEPEAK)))
 		return fail (MTR_ERR_UNSUPPORTED, "EBU / TRUEPEAK need stereo frames (the reference's EBUr128 plugin is stereo only)");
-	if (cfg->meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST))
-		return fail (MTR_ERR_UNSUPPORTED, "BITSTATS / SIGDIST are not built yet (SURVEY.md §8f)");
+	if ((cfg->meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && cfg->n_channels != 1)
+		return fail (MTR_ERR_UNSUPPORTED, "BITSTATS / SIGDIST take mono streams (the reference's bitmeter / SigDistHist are mono plugins)");
 	if (cfg->tune_run != 0 && cfg->tune_run != 13 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 13 or 39");
 
 	int ndev = 0;
@@ -249,6 +251,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->stage.release (); e->tile_start.release (); e->seg_tile.release (); e->frag_tile.release ();
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
 	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release ();
+	e->bim.release (); e->sdh.release ();
 	delete e;
 }
 
@@ -272,6 +275,62 @@ int mtr_engine_reset (mtr_engine* e)
 	e->integr = false;
 	e->hist_cur = 0;
 	e->last_n_frag = 0;
+	if (e->cfg.meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) return mtr_engine_intstat_reset (e);
+	return MTR_OK;
+}
+
+int mtr_engine_intstat_reset (mtr_engine* e)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	const uint32_t S = e->cfg.n_streams;
+	HIPCHK (hipStreamSynchronize (e->last_stream));
+	if (e->cfg.meters & MTR_METER_BITSTATS) {
+		std::vector<mtr_bitstats_state> h (S);
+		memset (h.data (), 0, S * sizeof (mtr_bitstats_state));
+		for (auto& b : h) { b.vmin = INFINITY; b.vmax = 0; }          // bim_clear, src/bitmeter.c:47-55
+		if (e->bim.reserve (S)) return fail (MTR_ERR_NOMEM, "hipMalloc bitstats state");
+		HIPCHK (hipMemcpy (e->bim.p, h.data (), S * sizeof (mtr_bitstats_state), hipMemcpyHostToDevice));
+	}
+	if (e->cfg.meters & MTR_METER_SIGDIST) {
+		if (e->sdh.reserve (S)) return fail (MTR_ERR_NOMEM, "hipMalloc sigdist state");
+		HIPCHK (hipMemset (e->sdh.p, 0, S * sizeof (mtr_sigdist_state)));
+	}
+	return MTR_OK;
+}
+
+int mtr_engine_bitstats (mtr_engine* e, uint32_t first, uint32_t count, int32_t* hist, int32_t* counters, float* minmax)
+{
+	if (!e || !(e->cfg.meters & MTR_METER_BITSTATS)) return fail (MTR_ERR_ARG, "no BITSTATS in this engine");
+	if ((uint64_t) first + count > e->cfg.n_streams) return fail (MTR_ERR_ARG, "stream range out of bounds");
+	if (count == 0) return MTR_OK;
+	int rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	std::vector<mtr_bitstats_state> h (count);
+	HIPCHK (hipMemcpy (h.data (), e->bim.p + first, count * sizeof (mtr_bitstats_state), hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < count; ++i) {
+		if (hist) memcpy (hist + (size_t) i * MTR_BIM_LAST, h[i].hist, sizeof (h[i].hist));
+		if (counters) { int32_t* c = counters + (size_t) i * 5; c[0] = h[i].n_zero; c[1] = h[i].n_pos; c[2] = h[i].n_nan; c[3] = h[i].n_inf; c[4] = h[i].n_den; }
+		if (minmax) { minmax[2 * i] = h[i].vmin; minmax[2 * i + 1] = h[i].vmax; }
+	}
+	return MTR_OK;
+}
+
+int mtr_engine_sigdist (mtr_engine* e, uint32_t first, uint32_t count, int32_t* bins, int32_t* peak, double* moments, int64_t* n)
+{
+	if (!e || !(e->cfg.meters & MTR_METER_SIGDIST)) return fail (MTR_ERR_ARG, "no SIGDIST in this engine");
+	if ((uint64_t) first + count > e->cfg.n_streams) return fail (MTR_ERR_ARG, "stream range out of bounds");
+	if (count == 0) return MTR_OK;
+	int rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	std::vector<mtr_sigdist_state> h (count);
+	HIPCHK (hipMemcpy (h.data (), e->sdh.p + first, count * sizeof (mtr_sigdist_state), hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < count; ++i) {
+		if (bins) memcpy (bins + (size_t) i * MTR_DIST_BIN, h[i].bins, sizeof (h[i].bins));
+		if (peak) { peak[2 * i] = h[i].peak_cnt; peak[2 * i + 1] = h[i].peak_bin; }
+		if (moments) { moments[3 * i] = h[i].avg; moments[3 * i + 1] = h[i].var_m; moments[3 * i + 2] = h[i].var_s; }
+		if (n) n[i] = h[i].count;
+	}
 	return MTR_OK;
 }
 
@@ -438,6 +497,10 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ba.n_streams = S; ba.n_channels = e->cfg.n_channels; ba.omega = e->omega;
 		if (mtr_launch_bank (ba, st)) return fail (MTR_ERR_HIP, "k_bank launch");
 	}
+	if (e->cfg.meters & MTR_METER_BITSTATS)
+		if (mtr_launch_bitstats (d_audio, stride, n_frames, e->bim.p, S, st)) return fail (MTR_ERR_HIP, "k_bitstats launch");
+	if (e->cfg.meters & MTR_METER_SIGDIST)
+		if (mtr_launch_sigdist (d_audio, stride, n_frames, e->sdh.p, S, st)) return fail (MTR_ERR_HIP, "k_sigdist launch");
 	const bool tpb = e->cfg.meters & MTR_METER_TPBALLIST;
 	if (tpb) {
 		mtr_tpb_args ta;

@@ -73,6 +73,21 @@ struct mtr_bank_args {
 	float           omega;
 };
 
+/* per-stream state of the integer paths */
+typedef struct mtr_bitstats_state {
+	int32_t hist[MTR_BIM_LAST];      /* src/uris.h:53-60 layout */
+	int32_t n_zero, n_pos, n_nan, n_inf, n_den;
+	float   vmin, vmax;              /* bim_min (init +inf), bim_max (init 0) */
+} mtr_bitstats_state;
+
+typedef struct mtr_sigdist_state {
+	int32_t  bins[MTR_DIST_BIN];
+	int32_t  peak_cnt, peak_bin;
+	double   avg, var_m, var_s;      /* hist_avgS (sum), hist_tmpS (mean), hist_varS (M2) */
+	int64_t  count, n_binned;
+	unsigned long long last[MTR_DIST_BIN];   /* 1-based index of the last sample per bin (peak tie-break) */
+} mtr_sigdist_state;
+
 typedef struct mtr_tpb_args mtr_tpb_args;
 struct mtr_tpb_args {
 	const float*    audio;        /* [S][stride][C] */
@@ -109,6 +124,10 @@ int  mtr_launch_gate (const mtr_gate_args& a, void* stream);
 int  mtr_launch_state_init (mtr_stream_state* st, int32_t* hist, uint32_t n_streams, int what, void* stream);
 int  mtr_launch_bank (const mtr_bank_args& a, void* stream);
 int  mtr_launch_tpb (const mtr_tpb_args& a, void* stream);
+int  mtr_launch_bitstats (const float* audio, uint64_t stride, uint64_t n_frames, mtr_bitstats_state* out,
+                          uint32_t n_streams, void* stream);
+int  mtr_launch_sigdist (const float* audio, uint64_t stride, uint64_t n_frames, mtr_sigdist_state* out,
+                         uint32_t n_streams, void* stream);
 int  mtr_launch_history_mono (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
                               float* hist_out, uint32_t n_streams, void* stream);
 uint32_t mtr_aggregate_parts (uint32_t n_streams);

@@ -12,6 +12,8 @@ import re
 import numpy as np
 
 METER_EBU, METER_TRUEPEAK, METER_SPECTR30, METER_TPBALLIST = 0x01, 0x02, 0x04, 0x08
+METER_BITSTATS, METER_SIGDIST = 0x10, 0x20
+BIM_LAST, DIST_BIN = 584, 361
 HIST_LEN, NBANDS = 751, 30
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -81,6 +83,9 @@ def _load():
     L.mtr_engine_fragment_powers.argtypes = [vp, u32, u32, vp, u32, C.POINTER(u32)]
     L.mtr_engine_spectrum.argtypes = [vp, u32, u32, vp, vp, vp, vp]
     L.mtr_engine_aggregate_device.argtypes = [vp, vp, vp, vp]
+    L.mtr_engine_bitstats.argtypes = [vp, u32, u32, vp, vp, vp]
+    L.mtr_engine_sigdist.argtypes = [vp, u32, u32, vp, vp, vp, vp]
+    L.mtr_engine_intstat_reset.argtypes = [vp]
     L.mtr_hist_loudness.argtypes = [vp, vp] + [C.POINTER(f32)] * 5
     L.mtr_hist_loudness.restype = None
     L.mtr_engine_timing_enable.argtypes = [vp, C.c_int]
@@ -237,6 +242,28 @@ class Engine:
         a = [np.zeros((count, NBANDS), np.float32) for _ in range(4)]
         _check(lib.mtr_engine_spectrum(self._h, first, count, *[x.ctypes.data for x in a]), "spectrum")
         return dict(val=a[0], max=a[1], val_db=a[2], max_db=a[3])
+
+    def bitstats(self, first=0, count=None):
+        count = self.n_streams - first if count is None else count
+        hist = np.zeros((count, BIM_LAST), np.int32)
+        cnt = np.zeros((count, 5), np.int32)
+        mm = np.zeros((count, 2), np.float32)
+        _check(lib.mtr_engine_bitstats(self._h, first, count, hist.ctypes.data, cnt.ctypes.data, mm.ctypes.data), "bitstats")
+        return dict(hist=hist, counters=cnt, vmin=mm[:, 0], vmax=mm[:, 1])
+
+    def sigdist(self, first=0, count=None):
+        count = self.n_streams - first if count is None else count
+        bins = np.zeros((count, DIST_BIN), np.int32)
+        peak = np.zeros((count, 2), np.int32)
+        mom = np.zeros((count, 3), np.float64)
+        n = np.zeros(count, np.int64)
+        _check(lib.mtr_engine_sigdist(self._h, first, count, bins.ctypes.data, peak.ctypes.data, mom.ctypes.data,
+                                      n.ctypes.data), "sigdist")
+        return dict(bins=bins, peak_cnt=peak[:, 0], peak_bin=peak[:, 1], avg=mom[:, 0], var_m=mom[:, 1],
+                    var_s=mom[:, 2], count=n)
+
+    def intstat_reset(self):
+        _check(lib.mtr_engine_intstat_reset(self._h), "intstat_reset")
 
     def aggregate_device(self, hist_ptr, max_ptr, stream=0):
         _check(lib.mtr_engine_aggregate_device(self._h, hist_ptr, max_ptr, stream), "aggregate_device")
