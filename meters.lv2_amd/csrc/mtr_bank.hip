@@ -21,7 +21,8 @@
 
 __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 {
-	__shared__ float mix[BANK_SPB][BANK_CHUNK];
+	__shared__ double mix[BANK_SPB][BANK_CHUNK];   // mono mix + the +-1e-12 anti-denormal toggle, as double
+	__shared__ int    par0[BANK_SPB];
 
 	const int tid  = threadIdx.x;
 	const int grp  = tid >> 5;                 // stream slot within the block
@@ -32,7 +33,6 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 	double W[6][5];
 	double z[12];
 	float  val = 0.f, mx = 0.f;
-	int    par = 0;
 	if (live) {
 #pragma unroll
 		for (int i = 0; i < 6; ++i)
@@ -42,7 +42,6 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 		for (int i = 0; i < 12; ++i) z[i] = a.z[((size_t) s * MTR_NBANDS + band) * 12 + i];
 		val = a.val[(size_t) s * MTR_NBANDS + band];
 		mx  = a.mx[(size_t) s * MTR_NBANDS + band];
-		par = a.ac[s];
 	} else {
 #pragma unroll
 		for (int i = 0; i < 6; ++i)
@@ -52,6 +51,8 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 		for (int i = 0; i < 12; ++i) z[i] = 0;
 	}
 	const float omega = a.omega;
+	if (tid < BANK_SPB) { const uint32_t sg = blockIdx.x * BANK_SPB + tid; par0[tid] = sg < a.n_streams ? a.ac[sg] : 0; }
+	__syncthreads ();
 
 	for (uint64_t base = 0; base < a.n_frames; base += BANK_CHUNK) {
 		const int nf = (int) min ((uint64_t) BANK_CHUNK, a.n_frames - base);
@@ -68,19 +69,29 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 					m = a.audio[(size_t) sg * a.stride + base + tid];
 				}
 			}
-			mix[g][tid] = m;
+			// bandpass_process toggles `ac` before use: sample i of the call gets +1e-12 when ac0 ^ 1 ^ (i & 1)
+			const int pz = par0[g] ^ 1 ^ (int) ((base + tid) & 1);
+			mix[g][tid] = (double) m + (pz ? 1e-12 : -1e-12);       // spectr.c:81-82
 		}
 		__syncthreads ();
 
 		for (int n = 0; n < nf; ++n) {
-			// bandpass_process: toggle, +-1e-12, six sections (spectr.c:78-87)
-			par ^= 1;
-			double out = (double) mix[grp][n] + (par ? 1e-12 : -1e-12);
+			// six TDF-II sections (spectr.c:68-76).  Section 0 carries the normalisation g: numerator
+			// g (1, 2, 1); sections 1-5 have (1, +-2, 1): b0 in = b2 in = in and b1 in = +-2 in are exact, so
+			// sharing the product changes nothing but the operation count (26 instead of 31 fp64 ops).
+			double out = mix[grp][n];
+			{
+				const double gi = W[0][0] * out;
+				const double y = gi + z[0];
+				z[0] = fma (-W[0][3], y, fma (2.0, gi, z[1]));
+				z[1] = fma (-W[0][4], y, gi);
+				out = y;
+			}
 #pragma unroll
-			for (int i = 0; i < 6; ++i) {
-				const double y = W[i][0] * out + z[2 * i];
-				z[2 * i]     = W[i][1] * out - W[i][3] * y + z[2 * i + 1];
-				z[2 * i + 1] = W[i][2] * out - W[i][4] * y;
+			for (int i = 1; i < 6; ++i) {
+				const double y = out + z[2 * i];
+				z[2 * i]     = fma (-W[i][3], y, fma (W[i][1], out, z[2 * i + 1]));
+				z[2 * i + 1] = fma (-W[i][4], y, out);
 				out = y;
 			}
 			const float v = (float) out;
@@ -102,7 +113,7 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 		}
 		a.val[(size_t) s * MTR_NBANDS + band] = val + 1e-20f;
 		a.mx[(size_t) s * MTR_NBANDS + band]  = mx;
-		if (band == 0) a.ac[s] = par;
+		if (band == 0) a.ac[s] = par0[grp] ^ (int) (a.n_frames & 1);
 	}
 }
 
