@@ -104,13 +104,26 @@ static int upload_consts (mtr_engine* e)
 	mtr_setup_kweight_matrix (e->kw, A, B);
 	for (int i = 0; i < 16; ++i) P[i] = (i % 5 == 0) ? 1.0 : 0.0;
 	for (int i = 0; i < e->run; ++i) mat4_mul (A, P, P);
-	float m[6 * 16];
+	const int K = e->run;
+	std::vector<float> m (96 + 4 * K + 4);
 	for (int d = 0; d < 6; ++d) {
 		for (int i = 0; i < 16; ++i) m[d * 16 + i] = (float) P[i];
 		mat4_mul (P, P, P);
 	}
-	if (e->scan_m.reserve (96)) return fail (MTR_ERR_NOMEM, "hipMalloc scan_m");
-	HIPCHK (hipMemcpy (e->scan_m.p, m, sizeof (m), hipMemcpyHostToDevice));
+	// end-state functionals of a K-frame run from zero state: F[n] = A^(K-1-n) B, n = 0..K-1, and the
+	// constant response to the +1e-15f bias, e0 = (sum_n A^(K-1-n) B) * 1e-15
+	{
+		double v[4] = { B[0], B[1], B[2], B[3] }, acc[4] = { 0, 0, 0, 0 };
+		for (int n = K - 1; n >= 0; --n) {
+			for (int j = 0; j < 4; ++j) { m[96 + 4 * n + j] = (float) v[j]; acc[j] += v[j]; }
+			double w[4];
+			for (int i = 0; i < 4; ++i) w[i] = A[i * 4] * v[0] + A[i * 4 + 1] * v[1] + A[i * 4 + 2] * v[2] + A[i * 4 + 3] * v[3];
+			memcpy (v, w, sizeof (v));
+		}
+		for (int j = 0; j < 4; ++j) m[96 + 4 * K + j] = (float) (acc[j] * (double) 1e-15f);
+	}
+	if (e->scan_m.reserve (m.size ())) return fail (MTR_ERR_NOMEM, "hipMalloc scan_m");
+	HIPCHK (hipMemcpy (e->scan_m.p, m.data (), m.size () * sizeof (float), hipMemcpyHostToDevice));
 
 	float bp[100];
 	mtr_setup_bin_power (bp);
@@ -422,7 +435,7 @@ static int build_plan (mtr_engine* e, uint64_t N)
 	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail;
 	uint32_t maxlen = n_segs > 1 ? LT : 0;                      // warm-up tiles are full tiles
 	for (uint32_t j = 0; j < n_tiles; ++j) maxlen = std::max (maxlen, ts[j + 1] - ts[j]);
-	pl.buf_slots = (maxlen + 48 + 127) / 128 * 128;
+	pl.buf_slots = (maxlen + 48 + 13 + 127) / 128 * 128;        // + look-ahead frames of the FIR register tile
 	pl.valid = true;
 	return MTR_OK;
 }

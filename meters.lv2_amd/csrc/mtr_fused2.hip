@@ -136,7 +136,10 @@ __device__ __forceinline__ void fir_dense (const v2f* xs, int nvalid, float& pk_
 // where P = (g1[i] + g1[47-i]) / 2, M = (g1[i] - g1[47-i]) / 2, Q = g2[i]:  2 adds + 3 FMAs per
 // (output, i) instead of 6 FMAs -> 120 instead of 144 packed operations per stereo frame.
 // For output r and i = G*g + k:  a = xs[1 + r + i],  b = xs[48 + r - i].
-template <int R>
+// MASK = false: every one of the R outputs is a true output (the loader stages R look-ahead frames
+// past the tile end, so outputs beyond `nvalid` are simply the next tile's first outputs computed
+// early — harmless under max).  MASK = true only for the last tile of a call.
+template <int R, bool MASK>
 __device__ __forceinline__ void fir_sym (const v2f* xs, int nvalid, float& pk_l, float& pk_r)
 {
 	constexpr int G = 6;                         // mirror pairs per SGPR tap group
@@ -169,11 +172,19 @@ __device__ __forceinline__ void fir_sym (const v2f* xs, int nvalid, float& pk_l,
 	for (int r = 0; r < R; ++r) {
 		const v2f x0 = xs[24 + r];               // phase 0 = identity: x[n - 24]
 		const v2f y1 = aS[r] + aD[r], y3 = aS[r] - aD[r];
-		const bool ok = r < nvalid;
-		const float ml = fmaxf (fmaxf (fabsf (y1.x), fabsf (y3.x)), fmaxf (fabsf (aQ[r].x), fabsf (x0.x)));
-		const float mr = fmaxf (fmaxf (fabsf (y1.y), fabsf (y3.y)), fmaxf (fabsf (aQ[r].y), fabsf (x0.y)));
-		pk_l = fmaxf (pk_l, ok ? ml : 0.f);
-		pk_r = fmaxf (pk_r, ok ? mr : 0.f);
+		if (MASK) {
+			const bool ok = r < nvalid;
+			const float ml = fmaxf (fmaxf (fabsf (y1.x), fabsf (y3.x)), fmaxf (fabsf (aQ[r].x), fabsf (x0.x)));
+			const float mr = fmaxf (fmaxf (fabsf (y1.y), fabsf (y3.y)), fmaxf (fabsf (aQ[r].y), fabsf (x0.y)));
+			pk_l = fmaxf (pk_l, ok ? ml : 0.f);
+			pk_r = fmaxf (pk_r, ok ? mr : 0.f);
+		} else {
+			// two v_max3_f32 per channel (|.| is a free source modifier)
+			pk_l = fmaxf (fmaxf (pk_l, fabsf (y1.x)), fabsf (y3.x));
+			pk_l = fmaxf (fmaxf (pk_l, fabsf (aQ[r].x)), fabsf (x0.x));
+			pk_r = fmaxf (fmaxf (pk_r, fabsf (y1.y)), fabsf (y3.y));
+			pk_r = fmaxf (fmaxf (pk_r, fabsf (aQ[r].y)), fabsf (x0.y));
+		}
 	}
 }
 
@@ -216,10 +227,10 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 	auto stage = [&] (int jj, v2f* buf) {
 		int64_t t0; int len;
 		tile_of (jj, t0, len);
-		const int nslot = len + 48;
+		const int nslot = len + 48 + R;           // R look-ahead frames: the FIR epilogue needs no masks
 		// 16-byte pairs need an even first frame; the one tile that ends on an odd final frame of the
 		// call cannot fetch that frame as half of a pair without reading past the stream: plain path.
-		const bool tail_odd = (t0 + len == (int64_t) a.n_frames) && (a.n_frames & 1);
+		const bool tail_odd = (t0 + len + R >= (int64_t) a.n_frames) && (a.n_frames & 1);
 		if (t0 >= 48 && src_even && ((t0 & 1) == 0) && !tail_odd) {
 			// LDS-DMA, 16 bytes (two frames) per lane per instruction, 1 KiB per wave-instruction.
 			// Source addresses past the end of the call are clamped (those slots are never consumed).
@@ -275,10 +286,32 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 				const int rl = min (max (len - run0, 0), K);
 				const v2f* const xr = cur + 48 + run0;
 
-				// pass 1: this lane's run from zero state (lane 0 from the carried state)
+				// pass 1: end state of this lane's run from a zero start state.  Only the end state is
+				// needed, and it is a linear functional of the K inputs, e = sum_n A^(K-1-n) B x_n (+ the
+				// constant response to the 1e-15f bias): 4 FMAs per frame with wave-uniform coefficients
+				// instead of the 11-operation recurrence.  A partial run (the last active lane) is
+				// skipped: nothing to its right consumes its end state.  Lane 0 adds A^K * carried state.
 				v2f z1 = 0, z2 = 0, z3 = 0, z4 = 0;
-				if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
-				for (int n = 0; n < rl; ++n) { v2f y; KW_STEP (xr[n], y); (void) y; }
+				if (rl == K) {
+					const float* F = a.scan_m + 96;
+					z1 = F[4 * K + 0]; z2 = F[4 * K + 1]; z3 = F[4 * K + 2]; z4 = F[4 * K + 3];
+#pragma unroll 1
+					for (int g = 0; g < K; g += R) {          // R frames at a time: 4R coefficients in SGPRs
+#pragma unroll
+						for (int j = 0; j < R; ++j) {
+							const v2f x = xr[g + j];
+							const float* Fn = F + 4 * (g + j);
+							z1 += Fn[0] * x; z2 += Fn[1] * x; z3 += Fn[2] * x; z4 += Fn[3] * x;
+						}
+					}
+				}
+				if (lane == 0) {
+					const float* M = a.scan_m;
+					z1 += M[0] * k1 + M[1] * k2;
+					z2 += M[4] * k1 + M[5] * k2;
+					z3 += M[8] * k1 + M[9] * k2 + M[10] * k3 + M[11] * k4;
+					z4 += M[12] * k1 + M[13] * k2 + M[14] * k3 + M[15] * k4;
+				}
 
 				// wave scan (Hillis-Steele): v_l <- sum_{j<=l} (A^K)^(l-j) e_j.  A is block lower
 				// triangular (stage 1 does not see stage 2), so rows 0,1 only need columns 0,1.
@@ -332,8 +365,17 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 				const int rlw = min (max (len - m0, 0), R);        // valid outputs of this lane's register tile
 				if (rlw > 0) {
 					if (SYM) {
-						fir_sym<7> (cur + m0, min (rlw, 7), pk_l, pk_r);
-						if (rlw > 7) fir_sym<6> (cur + m0 + 7, rlw - 7, pk_l, pk_r);
+						if (a.tile_start[jt0 + jj + 1] == (uint32_t) a.n_frames) {
+							// last tile of the call: frames past its end do not exist yet
+							fir_sym<7, true> (cur + m0, min (rlw, 7), pk_l, pk_r);
+							if (rlw > 7) fir_sym<6, true> (cur + m0 + 7, rlw - 7, pk_l, pk_r);
+						} else {
+							fir_sym<7, false> (cur + m0, 7, pk_l, pk_r);
+							// pin the first tile's maxima here: otherwise LLVM sinks its epilogue below the
+							// second tile's loop and keeps 42 accumulator registers alive across it
+							asm volatile ("" : "+v"(pk_l), "+v"(pk_r));
+							fir_sym<6, false> (cur + m0 + 7, 6, pk_l, pk_r);
+						}
 					} else {
 						fir_dense<R> (cur + m0, rlw, pk_l, pk_r);
 					}
