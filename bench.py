@@ -168,12 +168,27 @@ def main():
         if tq["calls"] and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
             k_ms = tq["ms_fused"] / tq["calls"]
             achieved = S * T * BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), valid for the
+            # profiled workload only; the counters cannot be read from inside this process
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                w = tj["workload"]
+                if (args.meters, S, T) == (w["meters"], w["streams_per_gpu"], w["frames_per_stream"]):
+                    traffic = tj["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
+            # the roofline that actually binds: packed fp32 VALU. Useful work = 120 (mirror-symmetric
+            # interpolator) + 23 (K-weighting, two passes) packed operations per stereo frame
+            valu_ops = 143.0 * S * T / (k_ms * 1e-3) * 2 * 2        # flop/s: 2 lanes x FMA
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "k_fused", "kernel_ms": k_ms, "gate_ms": tq["ms_gate"] / tq["calls"],
-                               "bank_ms": tq["ms_bank"] / tq["calls"],
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "k_fused2", "kernel_ms": k_ms, "gate_ms": tq["ms_gate"] / tq["calls"],
                                "algorithmic_bytes_per_launch": S * T * BYTES_PER_FRAME,
-                               "note": "dense 3-phase FIR is fp32-VALU bound: 288 FMA/frame caps at ~27% of HBM peak"}
+                               "binding_roofline": {"bound": "fp32 VALU (v_pk_fma_f32)", "achieved_tflops": valu_ops / 1e12,
+                                                    "peak_tflops": 157.3, "frac": valu_ops / 157.3e12},
+                               "note": "fp32-VALU bound, not HBM bound: the 4x interpolator alone needs 120 packed "
+                                       "VALU ops per 8-byte frame (SURVEY.md 8d: ceiling ~27% of HBM peak)"}
         elif tq["calls"] and tq["ms_bank"] > 0:
             k_ms = tq["ms_bank"] / tq["calls"]
             achieved = S * T * BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9

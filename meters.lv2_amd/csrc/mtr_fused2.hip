@@ -188,7 +188,7 @@ __device__ __forceinline__ void fir_sym (const v2f* xs, int nvalid, float& pk_l,
 	}
 }
 
-template <int K, int R, bool EBU, bool TP, bool SYM>
+template <int K, int R, bool EBU, bool TP, bool SYM, bool ROT>
 __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args a)
 {
 	static_assert (K == 3 * R && (K & 1) == 1, "three FIR waves x R outputs per lane run; odd lane stride");
@@ -238,6 +238,7 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 			for (int i = 0; i < nslot; i += 128) {
 				int64_t f = t0 - 48 + i + 2 * lane;
 				f = f > fmax ? (fmax & ~(int64_t) 1) : f;
+				if (i + 2 * lane < nslot)       // lanes past the tile write nothing (the carry slots live up there)
 				__builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void*) (src + f),
 				                                  (__attribute__ ((address_space (3))) void*) (buf + i), 16, 0, 0);
 			}
@@ -260,8 +261,146 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
 	};
 
-	if (wid == LDR) {
-		// =================== loader + K-filter wave ===================
+	// ---- K-filter of one tile (held in `cur`) by the calling wave; k1..k4 = carried state in / out ----
+	auto kfilter_tile = [&] (const v2f* cur, int jj, int len, bool warm, v2f& k1, v2f& k2, v2f& k3, v2f& k4) {
+		const int run0 = lane * K;
+		const int rl = min (max (len - run0, 0), K);
+		const v2f* const xr = cur + 48 + run0;
+
+		// pass 1: end state of this lane's run from a zero start state.  Only the end state is
+		// needed, and it is a linear functional of the K inputs, e = sum_n A^(K-1-n) B x_n (+ the
+		// constant response to the 1e-15f bias): 4 FMAs per frame with wave-uniform coefficients
+		// instead of the 11-operation recurrence.  A partial run (the last active lane) is
+		// skipped: nothing to its right consumes its end state.  Lane 0 adds A^K * carried state.
+		v2f z1 = 0, z2 = 0, z3 = 0, z4 = 0;
+		if (rl == K) {
+			const float* F = a.scan_m + 96;
+			z1 = F[4 * K + 0]; z2 = F[4 * K + 1]; z3 = F[4 * K + 2]; z4 = F[4 * K + 3];
+#pragma unroll 1
+			for (int g = 0; g < K; g += R) {          // R frames at a time: 4R coefficients in SGPRs
+#pragma unroll
+				for (int j = 0; j < R; ++j) {
+					const v2f x = xr[g + j];
+					const float* Fn = F + 4 * (g + j);
+					z1 += Fn[0] * x; z2 += Fn[1] * x; z3 += Fn[2] * x; z4 += Fn[3] * x;
+				}
+			}
+		}
+		if (lane == 0) {
+			const float* M = a.scan_m;
+			z1 += M[0] * k1 + M[1] * k2;
+			z2 += M[4] * k1 + M[5] * k2;
+			z3 += M[8] * k1 + M[9] * k2 + M[10] * k3 + M[11] * k4;
+			z4 += M[12] * k1 + M[13] * k2 + M[14] * k3 + M[15] * k4;
+		}
+
+		// wave scan (Hillis-Steele): v_l <- sum_{j<=l} (A^K)^(l-j) e_j.  A is block lower
+		// triangular (stage 1 does not see stage 2), so rows 0,1 only need columns 0,1.
+#pragma unroll
+		for (int d = 0; d < 6; ++d) {
+			const int off = 1 << d;
+			const float* M = a.scan_m + d * 16;
+			v2f w1 = shfl_up2 (z1, off), w2 = shfl_up2 (z2, off), w3 = shfl_up2 (z3, off), w4 = shfl_up2 (z4, off);
+			if (lane < off) { w1 = 0; w2 = 0; w3 = 0; w4 = 0; }
+			z1 += M[0] * w1;  z1 += M[1] * w2;
+			z2 += M[4] * w1;  z2 += M[5] * w2;
+			z3 += M[8] * w1;  z3 += M[9] * w2;  z3 += M[10] * w3; z3 += M[11] * w4;
+			z4 += M[12] * w1; z4 += M[13] * w2; z4 += M[14] * w3; z4 += M[15] * w4;
+		}
+
+		if (warm) {
+			k1 = bcast2 (z1, 63); k2 = bcast2 (z2, 63); k3 = bcast2 (z3, 63); k4 = bcast2 (z4, 63);
+		} else {
+			// pass 2: from the true start state (end state of the lane to the left), sum y^2
+			z1 = shfl_up2 (z1, 1); z2 = shfl_up2 (z2, 1); z3 = shfl_up2 (z3, 1); z4 = shfl_up2 (z4, 1);
+			if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
+			v2f sj = 0;
+			for (int n = 0; n < rl; ++n) { v2f y; KW_STEP (xr[n], y); sj += y * y; }
+			const float sl = wave_sum (sj.x), sr = wave_sum (sj.y);
+			if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = a.gain_l * sl + a.gain_r * sr;
+			const int last = (len - 1) / K;       // the lane holding the state after the last frame
+			k1 = bcast2 (z1, last); k2 = bcast2 (z2, last); k3 = bcast2 (z3, last); k4 = bcast2 (z4, last);
+		}
+		// ebu_r128_proc.cc:331-334: non-finite states are dropped at block ends
+		k1 = scrub (k1); k2 = scrub (k2); k3 = scrub (k3); k4 = scrub (k4);
+	};
+
+	// ---- interpolator sub-run `w` (0..2) of one tile: outputs m = lane*K + R*w + r.  Window element j of
+	//      output r is frame m - 47 + j, i.e. slot lane*K + R*w + 1 + r + j (frame t0 sits at slot 48) ----
+	auto fir_tile = [&] (const v2f* cur, int jj, int w, float& pk_l, float& pk_r) {
+		const int m0 = lane * K + R * w;
+		const int len = (int) (a.tile_start[jt0 + jj + 1] - a.tile_start[jt0 + jj]);
+		const int rlw = min (max (len - m0, 0), R);        // valid outputs of this lane's register tile
+		if (rlw <= 0) return;
+		if (SYM) {
+			if (a.tile_start[jt0 + jj + 1] == (uint32_t) a.n_frames) {
+				// last tile of the call: frames past its end do not exist yet
+				fir_sym<7, true> (cur + m0, min (rlw, 7), pk_l, pk_r);
+				if (rlw > 7) fir_sym<6, true> (cur + m0 + 7, rlw - 7, pk_l, pk_r);
+			} else {
+				fir_sym<7, false> (cur + m0, 7, pk_l, pk_r);
+				// pin the first tile's maxima here: otherwise LLVM sinks its epilogue below the
+				// second tile's loop and keeps 42 accumulator registers alive across it
+				asm volatile ("" : "+v"(pk_l), "+v"(pk_r));
+				fir_sym<6, false> (cur + m0 + 7, 6, pk_l, pk_r);
+			}
+		} else {
+			fir_dense<R> (cur + m0, rlw, pk_l, pk_r);
+		}
+	};
+
+	if (ROT) {
+		// =================== rotating roles: wave (tile + wid) & 3 == 3 loads + K-filters, the other
+		// three interpolate.  Over four tiles every wave does the same work, so the four SIMDs of a
+		// CU stay evenly loaded however the dispatcher placed the workgroup's waves.  The carried
+		// K-filter state travels through four LDS slots at the top of buffer 0.
+		v2f* const kst = buf0 + NB - 4;
+		float pk_l = 0.f, pk_r = 0.f;
+		if (wid == 3) {
+			v2f k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+			if (EBU && q == 0) {
+				k1 = v2f{st->kz[0], st->kz[1]}; k2 = v2f{st->kz[2], st->kz[3]};
+				k3 = v2f{st->kz[4], st->kz[5]}; k4 = v2f{st->kz[6], st->kz[7]};
+			}
+			if (lane == 0) { kst[0] = k1; kst[1] = k2; kst[2] = k3; kst[3] = k4; }
+			stage (-nwarm, buf0);
+			asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		block_barrier ();
+		for (int jj = -nwarm; jj < ntile; ++jj) {
+			const int it = jj + nwarm;
+			v2f* const cur = buf0 + (it & 1) * NB;
+			v2f* const nxt = buf0 + ((it & 1) ^ 1) * NB;
+			const int role = (wid + it) & 3;
+			if (role == 3) {
+				if (jj + 1 < ntile) stage (jj + 1, nxt);
+				if (EBU) {
+					int64_t t0; int len;
+					tile_of (jj, t0, len);
+					v2f k1 = kst[0], k2 = kst[1], k3 = kst[2], k4 = kst[3];
+					kfilter_tile (cur, jj, len, jj < 0, k1, k2, k3, k4);
+					if (lane == 0) { kst[0] = k1; kst[1] = k2; kst[2] = k3; kst[3] = k4; }
+				}
+				asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+			} else if (TP && jj >= 0) {
+				fir_tile (cur, jj, role, pk_l, pk_r);
+			}
+			block_barrier ();
+		}
+		if (EBU && q == a.n_segs - 1 && wid == 0 && lane == 0) {
+			st->kz[0] = kst[0].x; st->kz[1] = kst[0].y; st->kz[2] = kst[1].x; st->kz[3] = kst[1].y;
+			st->kz[4] = kst[2].x; st->kz[5] = kst[2].y; st->kz[6] = kst[3].x; st->kz[7] = kst[3].y;
+		}
+		if (TP) {
+			pk_l = wave_max (pk_l);
+			pk_r = wave_max (pk_r);
+			if (lane == 0) {
+				atomicMax (&st->tp_call[0], __float_as_uint (pk_l));
+				atomicMax (&st->tp_call[1], __float_as_uint (pk_r));
+			}
+		}
+	} else if (wid == LDR) {
+		// =================== fixed roles: loader + K-filter wave ===================
 		v2f k1 = 0, k2 = 0, k3 = 0, k4 = 0;        // carried K-filter state (wave-uniform)
 		if (EBU && q == 0) {
 			k1 = v2f{st->kz[0], st->kz[1]}; k2 = v2f{st->kz[2], st->kz[3]};
@@ -270,79 +409,14 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 		stage (-nwarm, buf0);
 		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 		block_barrier ();
-
 		for (int jj = -nwarm; jj < ntile; ++jj) {
 			const int par = (jj + nwarm) & 1;
 			v2f* const cur = buf0 + par * NB;
 			v2f* const nxt = buf0 + (par ^ 1) * NB;
 			int64_t t0; int len;
 			tile_of (jj, t0, len);
-			const bool warm = jj < 0;
-
 			if (jj + 1 < ntile) stage (jj + 1, nxt);          // in flight while this tile is filtered
-
-			if (EBU) {
-				const int run0 = lane * K;
-				const int rl = min (max (len - run0, 0), K);
-				const v2f* const xr = cur + 48 + run0;
-
-				// pass 1: end state of this lane's run from a zero start state.  Only the end state is
-				// needed, and it is a linear functional of the K inputs, e = sum_n A^(K-1-n) B x_n (+ the
-				// constant response to the 1e-15f bias): 4 FMAs per frame with wave-uniform coefficients
-				// instead of the 11-operation recurrence.  A partial run (the last active lane) is
-				// skipped: nothing to its right consumes its end state.  Lane 0 adds A^K * carried state.
-				v2f z1 = 0, z2 = 0, z3 = 0, z4 = 0;
-				if (rl == K) {
-					const float* F = a.scan_m + 96;
-					z1 = F[4 * K + 0]; z2 = F[4 * K + 1]; z3 = F[4 * K + 2]; z4 = F[4 * K + 3];
-#pragma unroll 1
-					for (int g = 0; g < K; g += R) {          // R frames at a time: 4R coefficients in SGPRs
-#pragma unroll
-						for (int j = 0; j < R; ++j) {
-							const v2f x = xr[g + j];
-							const float* Fn = F + 4 * (g + j);
-							z1 += Fn[0] * x; z2 += Fn[1] * x; z3 += Fn[2] * x; z4 += Fn[3] * x;
-						}
-					}
-				}
-				if (lane == 0) {
-					const float* M = a.scan_m;
-					z1 += M[0] * k1 + M[1] * k2;
-					z2 += M[4] * k1 + M[5] * k2;
-					z3 += M[8] * k1 + M[9] * k2 + M[10] * k3 + M[11] * k4;
-					z4 += M[12] * k1 + M[13] * k2 + M[14] * k3 + M[15] * k4;
-				}
-
-				// wave scan (Hillis-Steele): v_l <- sum_{j<=l} (A^K)^(l-j) e_j.  A is block lower
-				// triangular (stage 1 does not see stage 2), so rows 0,1 only need columns 0,1.
-#pragma unroll
-				for (int d = 0; d < 6; ++d) {
-					const int off = 1 << d;
-					const float* M = a.scan_m + d * 16;
-					v2f w1 = shfl_up2 (z1, off), w2 = shfl_up2 (z2, off), w3 = shfl_up2 (z3, off), w4 = shfl_up2 (z4, off);
-					if (lane < off) { w1 = 0; w2 = 0; w3 = 0; w4 = 0; }
-					z1 += M[0] * w1;  z1 += M[1] * w2;
-					z2 += M[4] * w1;  z2 += M[5] * w2;
-					z3 += M[8] * w1;  z3 += M[9] * w2;  z3 += M[10] * w3; z3 += M[11] * w4;
-					z4 += M[12] * w1; z4 += M[13] * w2; z4 += M[14] * w3; z4 += M[15] * w4;
-				}
-
-				if (warm) {
-					k1 = bcast2 (z1, 63); k2 = bcast2 (z2, 63); k3 = bcast2 (z3, 63); k4 = bcast2 (z4, 63);
-				} else {
-					// pass 2: from the true start state (end state of the lane to the left), sum y^2
-					z1 = shfl_up2 (z1, 1); z2 = shfl_up2 (z2, 1); z3 = shfl_up2 (z3, 1); z4 = shfl_up2 (z4, 1);
-					if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
-					v2f sj = 0;
-					for (int n = 0; n < rl; ++n) { v2f y; KW_STEP (xr[n], y); sj += y * y; }
-					const float sl = wave_sum (sj.x), sr = wave_sum (sj.y);
-					if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = a.gain_l * sl + a.gain_r * sr;
-					const int last = (len - 1) / K;       // the lane holding the state after the last frame
-					k1 = bcast2 (z1, last); k2 = bcast2 (z2, last); k3 = bcast2 (z3, last); k4 = bcast2 (z4, last);
-				}
-				// ebu_r128_proc.cc:331-334: non-finite states are dropped at block ends
-				k1 = scrub (k1); k2 = scrub (k2); k3 = scrub (k3); k4 = scrub (k4);
-			}
+			if (EBU) kfilter_tile (cur, jj, len, jj < 0, k1, k2, k3, k4);
 			asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");   // tile j+1 has landed in `nxt`
 			block_barrier ();
 		}
@@ -351,36 +425,11 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 			st->kz[4] = k3.x; st->kz[5] = k3.y; st->kz[6] = k4.x; st->kz[7] = k4.y;
 		}
 	} else if (TP) {
-		// =================== FIR wave `wid` ===================
-		// outputs m = lane*K + R*wid + r.  Window element j of output r is frame m - 47 + j,
-		// i.e. slot lane*K + R*wid + 1 + r + j (frame t0 sits at slot 48).
+		// =================== fixed roles: FIR wave `wid` ===================
 		float pk_l = 0.f, pk_r = 0.f;
-		const int m0 = lane * K + R * wid;
 		block_barrier ();
 		for (int jj = -nwarm; jj < ntile; ++jj) {
-			if (jj >= 0) {
-				const int par = (jj + nwarm) & 1;
-				const v2f* const cur = buf0 + par * NB;
-				const int len = (int) (a.tile_start[jt0 + jj + 1] - a.tile_start[jt0 + jj]);
-				const int rlw = min (max (len - m0, 0), R);        // valid outputs of this lane's register tile
-				if (rlw > 0) {
-					if (SYM) {
-						if (a.tile_start[jt0 + jj + 1] == (uint32_t) a.n_frames) {
-							// last tile of the call: frames past its end do not exist yet
-							fir_sym<7, true> (cur + m0, min (rlw, 7), pk_l, pk_r);
-							if (rlw > 7) fir_sym<6, true> (cur + m0 + 7, rlw - 7, pk_l, pk_r);
-						} else {
-							fir_sym<7, false> (cur + m0, 7, pk_l, pk_r);
-							// pin the first tile's maxima here: otherwise LLVM sinks its epilogue below the
-							// second tile's loop and keeps 42 accumulator registers alive across it
-							asm volatile ("" : "+v"(pk_l), "+v"(pk_r));
-							fir_sym<6, false> (cur + m0 + 7, 6, pk_l, pk_r);
-						}
-					} else {
-						fir_dense<R> (cur + m0, rlw, pk_l, pk_r);
-					}
-				}
-			}
+			if (jj >= 0) fir_tile (buf0 + ((jj + nwarm) & 1) * NB, jj, wid, pk_l, pk_r);
 			block_barrier ();
 		}
 		pk_l = wave_max (pk_l);
@@ -392,7 +441,7 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 	}
 }
 
-template <int K, int R, bool SYM>
+template <int K, int R, bool SYM, bool ROT>
 static int launch2 (bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, hipStream_t st)
 {
 	const size_t lds = (size_t) 2 * a.buf_slots * sizeof (v2f);
@@ -400,22 +449,24 @@ static int launch2 (bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units
 	static bool raised = false;
 	if (!raised) {
 		const int mx = 160 * 1024;
-		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, true, SYM>,  hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, false, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, false, true, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, true, SYM, ROT>,  hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, true, false, SYM, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+		(void) hipFuncSetAttribute ((const void*) k_fused2<K, R, false, true, SYM, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
 		raised = true;
 	}
-	if (ebu && tp)  hipLaunchKernelGGL ((k_fused2<K, R, true, true, SYM>),  grid, dim3 (256), lds, st, a);
-	else if (ebu)   hipLaunchKernelGGL ((k_fused2<K, R, true, false, SYM>), grid, dim3 (64),  lds, st, a);
-	else            hipLaunchKernelGGL ((k_fused2<K, R, false, true, SYM>), grid, dim3 (256), lds, st, a);
+	if (ebu && tp)  hipLaunchKernelGGL ((k_fused2<K, R, true, true, SYM, ROT>),  grid, dim3 (256), lds, st, a);
+	else if (ebu)   hipLaunchKernelGGL ((k_fused2<K, R, true, false, SYM, ROT>), grid, dim3 (64),  lds, st, a);
+	else            hipLaunchKernelGGL ((k_fused2<K, R, false, true, SYM, ROT>), grid, dim3 (256), lds, st, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
 int mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream)
 {
 	switch (run) {
-	case 39: return a.fir_form == 1 ? launch2<39, 13, false> (ebu, tp, a, n_units, (hipStream_t) stream)
-	                                : launch2<39, 13, true> (ebu, tp, a, n_units, (hipStream_t) stream);
+	case 39:
+		if (a.fir_form == 1) return launch2<39, 13, false, false> (ebu, tp, a, n_units, (hipStream_t) stream);
+		if (a.rotate && ebu && tp) return launch2<39, 13, true, true> (ebu, tp, a, n_units, (hipStream_t) stream);
+		return launch2<39, 13, true, false> (ebu, tp, a, n_units, (hipStream_t) stream);
 	default: return -2;
 	}
 }

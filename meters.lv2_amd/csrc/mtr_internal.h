@@ -43,6 +43,7 @@ struct mtr_fused_args {
 	uint64_t        n_frames;     /* frames per stream in this call (bounds for staging) */
 	uint32_t        buf_slots;    /* wave-specialised kernel: 8-byte slots per LDS buffer (multiple of 128) */
 	uint32_t        fir_form;     /* 0 = mirror-symmetric form (120 ops/frame), 1 = dense 3 x 48 taps (144) */
+	uint32_t        rotate;       /* wave-specialised kernel: rotate the loader / K-filter role over the four waves */
 	float           a0, a1, a2, b1, b2, c3, c4;
 	float           gain_l, gain_r;
 };
