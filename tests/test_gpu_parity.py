@@ -352,15 +352,12 @@ def test_truepeak_ballistics_batch(M, oracle):
             e.process(x[:, p:p + (2500 if p == 0 else 3500)])
             r = e.results()
             got.append([[(r[s].tpb_level[c], r[s].tpb_peak[c]) for c in range(2)] for s in range(S)])
+    import ctypes as C
+    from _oracle import MoTp
     for s in range(S):
         for c in range(2):
             ch = np.ascontiguousarray(x[s, :, c])
-            want = np.concatenate([oracle.tp_process_seq(ch[:2500], 48000.0, 2500),
-                                   ])
-            # a fresh oracle object per channel processed in the same two blocks
-            import ctypes as C
-            from _oracle import MoTp
-            t = MoTp()
+            t = MoTp()          # a fresh oracle object per channel, fed the same two blocks
             oracle.lib.mo_tp_init(C.byref(t), 48000.0)
             m, p = C.c_float(), C.c_float()
             for i, (a, b) in enumerate(((0, 2500), (2500, 6000))):
@@ -369,4 +366,3 @@ def test_truepeak_ballistics_batch(M, oracle):
                 oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
                 assert abs(got[i][s][c][0] - m.value) < 2e-6 * max(1.0, m.value), (s, c, i)
                 assert abs(got[i][s][c][1] - p.value) < 2e-6 * max(1.0, p.value), (s, c, i)
-            assert want.shape == (1, 2)
