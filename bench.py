@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 wave per segment, 2 wave-specialised")
     ap.add_argument("--fir", type=int, default=0, help="0 auto (mirror-symmetric form), 1 dense 3x48 taps")
+    ap.add_argument("--prune", type=int, default=0, help="1 = exact true-peak pruning (identical result, data-dependent speed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
     agg_max = torch.zeros(4, dtype=torch.float32, device=dev)
 
     eng = M.Engine(S, fs, meters, n_channels=1 if mono else 2, device=local, tune_run=args.run,
-                   tune_segments=args.segments, tune_layout=args.layout, tune_fir=args.fir)
+                   tune_segments=args.segments, tune_layout=args.layout, tune_fir=args.fir, tune_prune=args.prune)
     eng.integr_start()
 
     def step():
@@ -208,6 +209,11 @@ def main():
             n = min(S, 192)
             out["cpu_baseline"] = cpu_baseline(buf[:n].cpu().numpy(), fs)
         out["programme"] = mdist.programme_summary(agg_hist, agg_max)
+        if args.prune:
+            c, k = eng.prune_stats()
+            out["prune"] = {"tile_passes": c, "skipped": k, "skipped_frac": k / max(c, 1),
+                            "note": "exact branch-and-bound on L1*max|x|: identical peaks, data-dependent speed; "
+                                    "NOT the default and not the dense headline number"}
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

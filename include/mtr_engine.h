@@ -63,7 +63,8 @@ typedef struct {
 	uint32_t tune_layout;    /* 0 = auto, 1 = one wave per stream segment, 2 = wave-specialised workgroups (run 39),
 	                          * 3 = as 2 with the loader / K-filter role rotating over the four waves */
 	uint32_t tune_fir;       /* interpolator form: 0 = auto (mirror-symmetric), 1 = dense 3 x 48 taps */
-	uint32_t reserved[1];
+	uint32_t tune_prune;     /* 1 = exact true-peak pruning (branch and bound on L1 * max|x|): identical result,
+	                          * data-dependent speed; off by default so the default timing is the dense one */
 } mtr_config;
 
 /* Per-stream results.  The first nine floats are Ebu_r128_proc's getters in
@@ -167,6 +168,8 @@ int  mtr_engine_timing_enable (mtr_engine* e, int on);
 /* Sum over the process calls since the last query: fused K-weight+true-peak kernel, gating kernel,
  * filter-bank kernel (ms) and the number of calls. Synchronises. */
 int  mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, float* ms_bank, uint32_t* calls);
+/* With tune_prune: interpolator tile passes considered / skipped since the engine was created. */
+int  mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped);
 /* K-weighting coefficients a0 a1 a2 b1 b2 c3 c4 at `sample_rate` (Ebu_r128_proc::detect_init,
  * ebumeter/ebu_r128_proc.cc:263-293) */
 int  mtr_kweight_coef (float sample_rate, float* out7);

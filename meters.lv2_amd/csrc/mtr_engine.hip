@@ -76,6 +76,8 @@ struct mtr_engine {
 	DevBuf<mtr_bitstats_state> bim;
 	DevBuf<mtr_sigdist_state>  sdh;
 	DevBuf<float>    fir_g;         // [3][48] taps in device memory (ballistics kernel)
+	DevBuf<uint32_t> prune_cnt;     // [2] interpolator tile passes considered / skipped
+	uint64_t         prune_tot[2] = { 0, 0 };
 	float            tpb_w[4];      // w1 w2 w3 g of TruePeakdsp::init
 	Plan             plan;
 	uint32_t         last_n_frag = 0;
@@ -137,7 +139,8 @@ static int upload_consts (mtr_engine* e)
 		for (int i = 0; i < 48; ++i)
 			g[ph - 1][i] = (i < 24) ? tab[24 * ph + i] : tab[24 * (4 - ph) + (47 - i)];
 	if (mtr_fused_upload_taps (&g[0][0]) || mtr_fused2_upload_taps (&g[0][0])) return fail (MTR_ERR_HIP, "hipMemcpyToSymbol c_fir");
-	if (e->fir_g.reserve (144)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_g");
+	if (e->fir_g.reserve (144) || e->prune_cnt.reserve (2)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_g");
+	HIPCHK (hipMemset (e->prune_cnt.p, 0, 8));
 	HIPCHK (hipMemcpy (e->fir_g.p, g, sizeof (g), hipMemcpyHostToDevice));
 	// TruePeakdsp::init, jmeters/truepeakdsp.cc:154-157 — float / float / double, stored as float
 	const float fs = e->cfg.sample_rate;
@@ -266,7 +269,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->stage.release (); e->tile_start.release (); e->seg_tile.release (); e->frag_tile.release ();
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
 	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release ();
-	e->bim.release (); e->sdh.release ();
+	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
 	delete e;
 }
 
@@ -488,6 +491,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.buf_slots = pl.buf_slots;
 		fa.fir_form = e->cfg.tune_fir;
 		fa.rotate = e->layout == 3;
+		fa.prune = e->cfg.tune_prune ? 1 : 0;
+		fa.prune_stats = e->prune_cnt.p;
 		const int lrc = e->layout >= 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
 		                               : mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st);
 		if (lrc) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());
@@ -684,6 +689,20 @@ int mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, v
 		return fail (MTR_ERR_NOMEM, "hipMalloc aggregate scratch");
 	if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, e->agg_hist.p, e->agg_max.p, d_hist, d_max, hip_stream))
 		return fail (MTR_ERR_HIP, "k_aggregate launch");
+	return MTR_OK;
+}
+
+int mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	int rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	uint32_t h[2];
+	HIPCHK (hipMemcpy (h, e->prune_cnt.p, 8, hipMemcpyDeviceToHost));
+	HIPCHK (hipMemset (e->prune_cnt.p, 0, 8));       // 32-bit device counters are drained into 64-bit totals
+	e->prune_tot[0] += h[0]; e->prune_tot[1] += h[1];
+	if (considered) *considered = e->prune_tot[0];
+	if (skipped) *skipped = e->prune_tot[1];
 	return MTR_OK;
 }
 

@@ -355,7 +355,28 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 		// CU stay evenly loaded however the dispatcher placed the workgroup's waves.  The carried
 		// K-filter state travels through four LDS slots at the top of buffer 0.
 		v2f* const kst = buf0 + NB - 4;
+		// Exact peak pruning (a.prune): every interpolated value obeys |y_ph(n)| <= L1_ph * max|x| over its
+		// 48-frame window, so a tile whose max|x| (halo and look-ahead included) times the largest L1
+		// norm cannot beat the running peak of this (stream, segment) needs no interpolation at all —
+		// the maximum is unchanged bit for bit.  The loader/K-filter wave scans tile j+1's max|x| in
+		// its slack once the DMA has landed; the result and the shared running peak live in three LDS
+		// slots at the top of buffer 1.
+		v2f* const tmaxv = buf0 + 2 * NB - 4;                 // [2] by tile parity
+		uint32_t* const gpk = reinterpret_cast<uint32_t*> (buf0 + 2 * NB - 2);   // running peak L, R (float bits)
+		const bool prune = TP && a.prune;
+		auto scan_tile = [&] (int jj, const v2f* buf, int par) {
+			int64_t t0; int len;
+			tile_of (jj, t0, len);
+			const int nslot = len + 48 + R;
+			float ml = 0.f, mr = 0.f;
+			const int i0 = 1 + lane * K, i1 = min (i0 + K, nslot);
+			for (int i = i0; i < i1; ++i) { const v2f x = buf[i]; ml = fmaxf (ml, fabsf (x.x)); mr = fmaxf (mr, fabsf (x.y)); }
+			ml = wave_max (ml); mr = wave_max (mr);
+			if (lane == 0) tmaxv[par] = v2f{ml, mr};
+		};
+		uint32_t n_done = 0, n_skip = 0;
 		float pk_l = 0.f, pk_r = 0.f;
+		if (wid == 0 && lane == 0) { gpk[0] = 0u; gpk[1] = 0u; }
 		if (wid == 3) {
 			v2f k1 = 0, k2 = 0, k3 = 0, k4 = 0;
 			if (EBU && q == 0) {
@@ -365,6 +386,7 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 			if (lane == 0) { kst[0] = k1; kst[1] = k2; kst[2] = k3; kst[3] = k4; }
 			stage (-nwarm, buf0);
 			asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+			if (prune) scan_tile (-nwarm, buf0, 0);
 		}
 		block_barrier ();
 		for (int jj = -nwarm; jj < ntile; ++jj) {
@@ -382,10 +404,34 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 					if (lane == 0) { kst[0] = k1; kst[1] = k2; kst[2] = k3; kst[3] = k4; }
 				}
 				asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+				if (prune && jj + 1 < ntile) scan_tile (jj + 1, nxt, (it & 1) ^ 1);
 			} else if (TP && jj >= 0) {
-				fir_tile (cur, jj, role, pk_l, pk_r);
+				bool skip = false;
+				if (prune) {
+					// 2.56833 = the largest L1 norm of the three branches (phase 2); the margin covers
+					// fp32 rounding of the bound and of the accumulated sums
+					const float LB = 2.5684f * 1.0001f;
+					const v2f tm = tmaxv[it & 1];
+					const float gl = __uint_as_float (gpk[0]), gr = __uint_as_float (gpk[1]);
+					skip = (LB * tm.x <= gl) && (LB * tm.y <= gr);
+				}
+				n_done++;
+				if (skip) {
+					n_skip++;
+				} else {
+					const float ol = pk_l, orr = pk_r;
+					fir_tile (cur, jj, role, pk_l, pk_r);
+					if (prune && __any ((pk_l > ol) || (pk_r > orr))) {
+						const float wl = wave_max (pk_l), wr = wave_max (pk_r);
+						if (lane == 0) { atomicMax (&gpk[0], __float_as_uint (wl)); atomicMax (&gpk[1], __float_as_uint (wr)); }
+					}
+				}
 			}
 			block_barrier ();
+		}
+		if (prune && lane == 0 && a.prune_stats) {
+			atomicAdd (&a.prune_stats[0], n_done);
+			atomicAdd (&a.prune_stats[1], n_skip);
 		}
 		if (EBU && q == a.n_segs - 1 && wid == 0 && lane == 0) {
 			st->kz[0] = kst[0].x; st->kz[1] = kst[0].y; st->kz[2] = kst[1].x; st->kz[3] = kst[1].y;

@@ -44,6 +44,8 @@ struct mtr_fused_args {
 	uint32_t        buf_slots;    /* wave-specialised kernel: 8-byte slots per LDS buffer (multiple of 128) */
 	uint32_t        fir_form;     /* 0 = mirror-symmetric form (120 ops/frame), 1 = dense 3 x 48 taps (144) */
 	uint32_t        rotate;       /* wave-specialised kernel: rotate the loader / K-filter role over the four waves */
+	uint32_t        prune;        /* exact peak pruning: skip the interpolator where L1 * max|x| cannot beat the running peak */
+	uint32_t*       prune_stats;  /* [2] register-tile passes considered / skipped (device counters), may be NULL */
 	float           a0, a1, a2, b1, b2, c3, c4;
 	float           gain_l, gain_r;
 };

@@ -28,7 +28,7 @@ class _Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("meters", C.c_uint32), ("n_streams", C.c_uint32),
                 ("n_channels", C.c_uint32), ("sample_rate", C.c_float), ("device", C.c_int32),
                 ("max_frames", C.c_uint32), ("tune_run", C.c_uint32), ("tune_segments", C.c_uint32),
-                ("tune_layout", C.c_uint32), ("tune_fir", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("tune_layout", C.c_uint32), ("tune_fir", C.c_uint32), ("tune_prune", C.c_uint32)]
 
 
 class StreamResult(C.Structure):
@@ -86,6 +86,7 @@ def _load():
     L.mtr_engine_bitstats.argtypes = [vp, u32, u32, vp, vp, vp]
     L.mtr_engine_sigdist.argtypes = [vp, u32, u32, vp, vp, vp, vp]
     L.mtr_engine_intstat_reset.argtypes = [vp]
+    L.mtr_engine_prune_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_hist_loudness.argtypes = [vp, vp] + [C.POINTER(f32)] * 5
     L.mtr_hist_loudness.restype = None
     L.mtr_engine_timing_enable.argtypes = [vp, C.c_int]
@@ -146,11 +147,11 @@ def synth_fill_device(ptr, n_streams, n_frames, stride, seed, fs=48000.0, kind=1
 
 class Engine:
     def __init__(self, n_streams, sample_rate=48000.0, meters=METER_EBU | METER_TRUEPEAK,
-                 n_channels=2, device=0, tune_run=0, tune_segments=0, tune_layout=0, tune_fir=0):
+                 n_channels=2, device=0, tune_run=0, tune_segments=0, tune_layout=0, tune_fir=0, tune_prune=0):
         cfg = _Config(struct_size=C.sizeof(_Config), meters=meters, n_streams=n_streams,
                       n_channels=n_channels, sample_rate=sample_rate, device=device,
                       max_frames=0, tune_run=tune_run, tune_segments=tune_segments,
-                      tune_layout=tune_layout, tune_fir=tune_fir)
+                      tune_layout=tune_layout, tune_fir=tune_fir, tune_prune=tune_prune)
         self._h = C.c_void_p()
         self.n_streams, self.meters, self.sample_rate = n_streams, meters, sample_rate
         _check(lib.mtr_engine_create(C.byref(cfg), C.byref(self._h)), "mtr_engine_create")
@@ -267,6 +268,11 @@ class Engine:
 
     def aggregate_device(self, hist_ptr, max_ptr, stream=0):
         _check(lib.mtr_engine_aggregate_device(self._h, hist_ptr, max_ptr, stream), "aggregate_device")
+
+    def prune_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib.mtr_engine_prune_stats(self._h, C.byref(a), C.byref(b)), "prune_stats")
+        return a.value, b.value
 
     def timing_enable(self, on=True):
         _check(lib.mtr_engine_timing_enable(self._h, int(on)), "timing_enable")

@@ -50,3 +50,34 @@ def test_variants_agree_and_match_oracle(M, oracle, segs, calls):
             assert abs(o9[s, 4] - ref[s]["out9"][4]) <= 0.01, (kw, s)
             assert np.allclose(pk[s], tp[s], rtol=2e-6), (kw, s)
             assert np.abs(hm[s] - ref[s]["hist_M"]).sum() <= 4, (kw, s)
+
+
+def test_exact_peak_pruning_changes_nothing_but_time(M, oracle):
+    """tune_prune skips interpolator tiles whose L1 * max|x| bound cannot beat the running peak:
+    peaks must be bit-identical to the dense run, on signals that prune a lot and that prune nothing."""
+    import _signals as sig
+    T = 48000 * 8
+    loud_then_quiet = sig.lcg_noise(T, 5, 0.5)
+    loud_then_quiet[48000:] *= np.float32(0.125)             # everything after 1 s is 18 dB down: prunable
+    ramp_up = sig.lcg_noise(T, 6, 0.5) * np.linspace(0.05, 1.0, T, dtype=np.float32)[:, None]   # peak keeps rising
+    steady = sig.lcg_noise(T, 7, 0.5)                        # stationary: nothing to prune
+    spike = np.zeros((T, 2), np.float32)
+    spike[T // 2, 0] = 1.0                                   # one impulse in silence, mid-tile
+    spike[T - 30, 1] = -0.75                                 # and one whose ringing crosses the last tiles
+    x = np.stack([loud_then_quiet, ramp_up.astype(np.float32), steady, spike])
+    res = {}
+    for prune in (0, 1):
+        for segs in (0, 4):
+            with M.Engine(4, 48000.0, M.METER_EBU | M.METER_TRUEPEAK, tune_prune=prune, tune_segments=segs) as e:
+                e.integr_start()
+                for a, b in ((0, 100000), (100000, T)):          # two calls: history + running state carry over
+                    e.process(x[:, a:b])
+                res[prune, segs] = (e.truepeak(), e.out9(), e.prune_stats())
+    for segs in (0, 4):
+        assert np.array_equal(res[0, segs][0], res[1, segs][0])           # identical peaks, bit for bit
+        assert np.array_equal(res[0, segs][1], res[1, segs][1])           # loudness untouched
+        done, skipped = res[1, segs][2]
+        assert done > 0 and skipped > 0.2 * done, (done, skipped)
+        assert res[0, segs][2] == (0, 0)
+    for s in range(4):
+        assert np.allclose(res[1, 0][0][s], oracle.tp(x[s], 48000.0, 8192), rtol=2e-6), s
