@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""tools/gen_ttl.py <bundle_dir> — write manifest.ttl + meters_amd.ttl for the in-scope plugins so a
+stock LV2 host can load meters.lv2_amd/lib/meters_amd.so as a bundle.
+
+Port indices, symbols and ranges are the reference's (lv2ttl/meters.lv2.ttl.in: VU :13-43 etc.,
+dBTP :1906-1975, EBUr128 :614-660, spectr30 :1292-1841), generated here from tables rather than
+copied.  The plugins keep the reference's URIs, so host sessions that reference them keep working;
+no UI is declared (the GUIs are out of scope)."""
+import os
+import sys
+
+MTR = "http://gareus.org/oss/lv2/meters#"
+BANDS = [25, 31, 40, 50, 63, 80, 100, 125, 160, 200, 250, 315, 400, 500, 630, 800, 1000, 1250, 1600, 2000,
+         2500, 3150, 4000, 5000, 6300, 8000, 10000, 12500, 16000, 20000]
+
+PREFIX = """@prefix atom: <http://lv2plug.in/ns/ext/atom#> .
+@prefix doap: <http://usefulinc.com/ns/doap#> .
+@prefix lv2:  <http://lv2plug.in/ns/lv2core#> .
+@prefix mtr:  <%s> .
+@prefix pg:   <http://lv2plug.in/ns/ext/port-groups#> .
+@prefix rdfs: <http://www.w3.org/2000/01/rdf-schema#> .
+@prefix rsz:  <http://lv2plug.in/ns/ext/resize-port#> .
+@prefix time: <http://lv2plug.in/ns/ext/time#> .
+@prefix urid: <http://lv2plug.in/ns/ext/urid#> .
+
+""" % MTR
+
+
+def ctl(idx, sym, name, direction, lo=None, hi=None, default=None):
+    s = "\t\ta lv2:ControlPort , lv2:%sPort ;\n\t\tlv2:index %d ;\n\t\tlv2:symbol \"%s\" ;\n\t\tlv2:name \"%s\" ;\n" % (
+        direction, idx, sym, name)
+    if default is not None:
+        s += "\t\tlv2:default %s ;\n" % default
+    if lo is not None:
+        s += "\t\tlv2:minimum %s ;\n\t\tlv2:maximum %s ;\n" % (lo, hi)
+    return s
+
+
+def audio(idx, sym, name, direction):
+    return "\t\ta lv2:AudioPort , lv2:%sPort ;\n\t\tlv2:index %d ;\n\t\tlv2:symbol \"%s\" ;\n\t\tlv2:name \"%s\" ;\n" % (
+        direction, idx, sym, name)
+
+
+def atom_port(idx, sym, name, direction, extra=""):
+    return ("\t\ta atom:AtomPort , lv2:%sPort ;\n\t\tatom:bufferType atom:Sequence ;\n\t\tlv2:designation lv2:control ;\n"
+            "%s\t\tlv2:index %d ;\n\t\tlv2:symbol \"%s\" ;\n\t\tlv2:name \"%s\" ;\n" % (direction, extra, idx, sym, name))
+
+
+def plugin(uri, name, comment, ports, extra=""):
+    body = " ] , [\n".join(ports)
+    return ("mtr:%s\n\ta lv2:Plugin , lv2:AnalyserPlugin , doap:Project ;\n\tdoap:license <http://usefulinc.com/doap/licenses/gpl> ;\n"
+            "\tdoap:name \"%s\" ;\n\tlv2:project <http://gareus.org/oss/lv2/meters> ;\n\tlv2:optionalFeature lv2:hardRTCapable ;\n%s"
+            "\tlv2:port [\n%s\t] ;\n\trdfs:comment \"%s\"\n\t.\n\n" % (uri, name, extra, body, comment))
+
+
+def spectr(stereo):
+    p = [ctl(i, "band%d" % b, "%d Hz" % b, "Output", -100.0, 6.0) for i, b in enumerate(BANDS)]
+    p += [ctl(30 + i, "max%d" % b, "%d Hz peak" % b, "Output", -100.0, 6.0) for i, b in enumerate(BANDS)]
+    p += [ctl(60, "UIspeed", "Integration speed", "Input", 0.02, 15.0, 1.0),
+          ctl(61, "UIreset", "Peak hold reset", "Input", -4.0, 4.0, -4.0),
+          ctl(62, "UIgain", "UI gain", "Input", -12.0, 32.0, 0.0),
+          ctl(63, "UImiscstate", "UI state", "Input", 0, 256, 1)]
+    if stereo:
+        p += [audio(64, "inL", "InL", "Input"), audio(65, "outL", "OutL", "Output"),
+              audio(66, "inR", "InR", "Input"), audio(67, "outR", "OutR", "Output")]
+    else:
+        p += [audio(64, "in", "In", "Input"), audio(65, "out", "Out", "Output")]
+    return p
+
+
+def main(out):
+    os.makedirs(out, exist_ok=True)
+    plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo"]
+    man = PREFIX + "".join("mtr:%s\n\ta lv2:Plugin ;\n\tlv2:binary <meters_amd.so> ;\n\trdfs:seeAlso <meters_amd.ttl> .\n\n" % p
+                           for p in plugs)
+    open(os.path.join(out, "manifest.ttl"), "w").write(man)
+
+    t = PREFIX
+    t += plugin("VUmono", "VU Meter (Mono, MI355X build)", "Volume unit meter; needle ballistics on the host CPU.",
+                [ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, -22.0), audio(1, "in", "In", "Input"),
+                 audio(2, "out", "Out", "Output"), ctl(3, "level1", "Level", "Output", 0.0, 1.0)])
+    t += plugin("VUstereo", "VU Meter (Stereo, MI355X build)", "Volume unit meter; needle ballistics on the host CPU.",
+                [ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, -22.0), audio(1, "inL", "InL", "Input"),
+                 audio(2, "outL", "OutL", "Output"), ctl(3, "levelL", "Level L", "Output", 0.0, 1.0),
+                 audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output"),
+                 ctl(6, "levelR", "Level R", "Output", 0.0, 1.0)])
+    t += plugin("EBUr128", "EBU R128 Meter (MI355X build)",
+                "Stereo loudness meter according to EBU R128 with 4x true peak; DSP on the GPU.",
+                [atom_port(0, "control", "UI to plugin communication", "Input", "\t\tatom:supports time:Position ;\n"),
+                 atom_port(1, "notify", "plugin to UI communication", "Output", "\t\trsz:minimumSize 4096 ;\n"),
+                 audio(2, "inL", "InL", "Input"), audio(3, "outL", "OutL", "Output"),
+                 audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output")],
+                extra="\tlv2:requiredFeature urid:map ;\n")
+    t += plugin("spectr30mono", "1/3 Octave Spectrum (Mono, MI355X build)", "30-band 1/3-octave analyser; DSP on the GPU.", spectr(False))
+    t += plugin("dBTPmono", "True Peak Meter (Mono, MI355X build)", "4x oversampled true-peak meter; DSP on the GPU.",
+                [ctl(0, "ref", "Reset / notify", "Input", -4.0, 4.0, -4.0), audio(1, "in", "In", "Input"),
+                 audio(2, "out", "Out", "Output"), ctl(3, "level1", "Level", "Output", 0.0, 1.0),
+                 ctl(4, "peak", "Peak", "Output", 0.0, 1.0)])
+    t += plugin("dBTPstereo", "True Peak Meter (Stereo, MI355X build)", "4x oversampled true-peak meter; DSP on the GPU.",
+                [ctl(0, "ref", "Reset / notify", "Input", -4.0, 4.0, -4.0), audio(1, "inL", "InL", "Input"),
+                 audio(2, "outL", "OutL", "Output"), ctl(3, "levelL", "Level L", "Output", 0.0, 1.0),
+                 audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output"),
+                 ctl(6, "levelR", "Level R", "Output", 0.0, 1.0), ctl(7, "peakL", "Peak L", "Output", 0.0, 1.0),
+                 ctl(8, "peakR", "Peak R", "Output", 0.0, 1.0)])
+    t += plugin("spectr30stereo", "1/3 Octave Spectrum (Stereo, MI355X build)", "30-band 1/3-octave analyser; DSP on the GPU.", spectr(True))
+    open(os.path.join(out, "meters_amd.ttl"), "w").write(t)
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "meters_amd.lv2")
