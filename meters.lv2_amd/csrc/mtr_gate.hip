@@ -144,8 +144,6 @@ __global__ __launch_bounds__ (256) void k_gate (const mtr_gate_args a)
 		const bool addS = a.integr && tid < nf && ((div2_0 + f_abs + 1) % 10 == 0);
 		if (addM && f_abs <= f_calc) hist_add (sh_hist[0], &sh_cnt[0], &sh_cnt[2], lm);
 		if (addS && f_abs <= f_calc) hist_add (sh_hist[1], &sh_cnt[1], &sh_cnt[3], ls);
-		sh_red[0][tid] = lm;
-		sh_red[1][tid] = ls;
 		__syncthreads ();
 
 		if (f_calc >= (int) base && f_calc < (int) base + nf) {
@@ -159,13 +157,10 @@ __global__ __launch_bounds__ (256) void k_gate (const mtr_gate_args a)
 		if (addM && f_abs > f_calc) hist_add (sh_hist[0], &sh_cnt[0], &sh_cnt[2], lm);
 		if (addS && f_abs > f_calc) hist_add (sh_hist[1], &sh_cnt[1], &sh_cnt[3], ls);
 
-		if (tid == 0) {
-			for (int i = 0; i < nf; ++i) {           // max-hold (order-free) and the last value
-				max_M = sh_red[0][i] > max_M ? sh_red[0][i] : max_M;
-				max_S = sh_red[1][i] > max_S ? sh_red[1][i] : max_S;
-			}
-			last_M = sh_red[0][nf - 1];
-			last_S = sh_red[1][nf - 1];
+		if (tid < nf) {                              // max-hold is order-free: per-lane, folded once at the end
+			max_M = lm > max_M ? lm : max_M;
+			max_S = ls > max_S ? ls : max_S;
+			if (f_abs == (int) a.n_frag - 1) { sh_red[0][0] = lm; sh_red[1][0] = ls; }   // the values a getter sees
 		}
 		__syncthreads ();
 		// slide the power window: keep the newest 64 as history for the next chunk
@@ -176,6 +171,19 @@ __global__ __launch_bounds__ (256) void k_gate (const mtr_gate_args a)
 		__syncthreads ();
 	}
 
+	// fold the per-lane maxima
+	if (a.n_frag > 0) { last_M = sh_red[0][0]; last_S = sh_red[1][0]; }
+	__syncthreads ();
+	sh_red[0][tid] = max_M; sh_red[1][tid] = max_S;
+	__syncthreads ();
+	for (int d = 128; d >= 1; d >>= 1) {
+		if (tid < d) {
+			sh_red[0][tid] = sh_red[0][tid + d] > sh_red[0][tid] ? sh_red[0][tid + d] : sh_red[0][tid];
+			sh_red[1][tid] = sh_red[1][tid + d] > sh_red[1][tid] ? sh_red[1][tid + d] : sh_red[1][tid];
+		}
+		__syncthreads ();
+	}
+	max_M = sh_red[0][0]; max_S = sh_red[1][0];
 	// tiles of the still-open fragment: partial power carried to the next call
 	if (tid == 0) {
 		float acc = (a.n_frag == 0) ? frpwr0 : 1e-30f;
