@@ -47,7 +47,7 @@ struct Plan {
 	uint64_t n_frames = 0;
 	uint32_t frcnt_in = 0;      // frames left in the open fragment when the call starts
 	uint32_t frcnt_out = 0;
-	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0, buf_slots = 0;
+	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0, buf_slots = 0, kw_slots = 0;
 	bool     valid = false;
 };
 
@@ -107,7 +107,16 @@ static int upload_consts (mtr_engine* e)
 	for (int i = 0; i < 16; ++i) P[i] = (i % 5 == 0) ? 1.0 : 0.0;
 	for (int i = 0; i < e->run; ++i) mat4_mul (A, P, P);
 	const int K = e->run;
-	std::vector<float> m (96 + 4 * K + 4);
+	std::vector<float> m (96 + 4 * K + 4 + 32 * 16);
+	{
+		// M^1 .. M^32 (M = A^K) for the row-broadcast steps of the DPP scan (mtr_wave.h), after the functionals
+		double Q[16];
+		memcpy (Q, P, sizeof (Q));
+		for (int p = 0; p < 32; ++p) {
+			for (int i = 0; i < 16; ++i) m[96 + 4 * K + 4 + 16 * p + i] = (float) Q[i];
+			mat4_mul (P, Q, Q);
+		}
+	}
 	for (int d = 0; d < 6; ++d) {
 		for (int i = 0; i < 16; ++i) m[d * 16 + i] = (float) P[i];
 		mat4_mul (P, P, P);
@@ -206,7 +215,7 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 		return fail (MTR_ERR_UNSUPPORTED, "EBU / TRUEPEAK need stereo frames (the reference's EBUr128 plugin is stereo only)");
 	if ((cfg->meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && cfg->n_channels != 1)
 		return fail (MTR_ERR_UNSUPPORTED, "BITSTATS / SIGDIST take mono streams (the reference's bitmeter / SigDistHist are mono plugins)");
-	if (cfg->tune_run != 0 && cfg->tune_run != 13 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 13 or 39");
+	if (cfg->tune_run != 0 && cfg->tune_run != 13 && cfg->tune_run != 19 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 13, 19 or 39");
 
 	int ndev = 0;
 	if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0)
@@ -220,10 +229,15 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	// layout 2 (wave-specialised workgroups, 39-frame lane runs) is the default; layout 1 is the
 	// first design (one wave per stream segment), kept for comparison and for 13-frame runs
 	// (auto = 3: roles rotate over the four waves; measured 1.7 % faster than fixed roles, profiles/r01d)
-	e->layout = cfg->tune_layout ? (int) cfg->tune_layout : (cfg->tune_run == 13 ? 1 : 3);
+	// layout 4 = k_kw, the K-weighting-only kernel (mtr_kw.hip): the default when no true peak is asked for
+	const bool kw_only = (cfg->meters & MTR_METER_EBU) && !(cfg->meters & MTR_METER_TRUEPEAK);
+	e->layout = cfg->tune_layout ? (int) cfg->tune_layout : (cfg->tune_run == 13 ? 1 : (kw_only ? 4 : 3));
 	e->run = cfg->tune_run ? (int) cfg->tune_run : 39;
-	if (e->layout >= 2 && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layouts 2 and 3 need tune_run 39"); }
-	if (e->layout > 3) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..3"); }
+	if (e->layout > 4) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..4"); }
+	if (e->layout == 4 && !kw_only) { delete e; return fail (MTR_ERR_ARG, "layout 4 is the EBU-only kernel"); }
+	if ((e->layout == 2 || e->layout == 3) && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layouts 2 and 3 need tune_run 39"); }
+	if (e->layout == 4 && e->run == 13) { delete e; return fail (MTR_ERR_ARG, "layout 4 needs tune_run 19 or 39"); }
+	if (e->layout == 1 && e->run == 19) { delete e; return fail (MTR_ERR_ARG, "tune_run 19 is layout 4 only"); }
 	e->fragm = (uint32_t) ((int) cfg->sample_rate / 20);     // ebu_r128_proc.cc:170
 	e->frcnt = e->fragm;
 	mtr_setup_kweight (cfg->sample_rate, e->kw);
@@ -442,6 +456,7 @@ static int build_plan (mtr_engine* e, uint64_t N)
 	for (uint32_t j = 0; j < n_tiles; ++j) maxlen = std::max (maxlen, ts[j + 1] - ts[j]);
 	// + look-ahead frames of the FIR register tile + 4 slots for the carried K-filter state (layout 3)
 	pl.buf_slots = (maxlen + 48 + 13 + 4 + 127) / 128 * 128;
+	pl.kw_slots = (maxlen + 1 + 127) / 128 * 128;               // k_kw: the tile + one frame of alignment slack
 	pl.valid = true;
 	return MTR_OK;
 }
@@ -488,12 +503,13 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.c3 = e->kw[5]; fa.c4 = e->kw[6];
 		fa.gain_l = 1.0f; fa.gain_r = 1.0f;                  // _chan_gain[0..1], ebu_r128_proc.cc:29
 		fa.n_frames = n_frames;
-		fa.buf_slots = pl.buf_slots;
+		fa.buf_slots = e->layout == 4 ? pl.kw_slots : pl.buf_slots;
 		fa.fir_form = e->cfg.tune_fir;
 		fa.rotate = e->layout == 3;
 		fa.prune = e->cfg.tune_prune ? 1 : 0;
 		fa.prune_stats = e->prune_cnt.p;
-		const int lrc = e->layout >= 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
+		const int lrc = e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
+		              : e->layout >= 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
 		                               : mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st);
 		if (lrc) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());
 		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }

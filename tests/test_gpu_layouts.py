@@ -52,6 +52,33 @@ def test_variants_agree_and_match_oracle(M, oracle, segs, calls):
             assert np.abs(hm[s] - ref[s]["hist_M"]).sum() <= 4, (kw, s)
 
 
+@pytest.mark.parametrize("fs", [48000.0, 44100.0])
+@pytest.mark.parametrize("segs", [0, 3])
+def test_kweighting_only_kernel(M, oracle, fs, segs):
+    """EBU without true peak runs k_kw (layout 4: one wave per segment, single LDS buffer, DPP scan), with
+    39- or 19-frame lane runs; same record as the fused kernel's K-filter role and as the oracle.  44.1 kHz
+    fragments are 2205 frames, so tiles start on odd frames; odd-sized calls end on odd frames."""
+    T = int(fs) * 6 + 1
+    calls = [1001, int(fs) * 3, 47, T - 1001 - int(fs) * 3 - 47]
+    x = np.stack([tri_noise(T, 300 + s, 2.0 ** -(s % 3), period=72000) for s in range(3)])
+    ref = [oracle.ebu(x[s], fs, 2400, want_frag=True) for s in range(3)]
+    for kw in (dict(tune_layout=3), dict(tune_layout=4), dict(tune_layout=4, tune_run=19), dict()):
+        with M.Engine(3, fs, M.METER_EBU, tune_segments=segs, **kw) as e:
+            e.integr_start()
+            pos, frags = 0, []
+            for n in calls:
+                e.process(x[:, pos:pos + n])
+                frags.append(e.fragment_powers())
+                pos += n
+            o9, fr = e.out9(), np.concatenate(frags, 1)
+            hm, _ = e.histograms()
+        for s in range(3):
+            assert np.allclose(fr[s], ref[s]["frag_power"], rtol=2e-5), (kw, s)
+            assert np.allclose(o9[s, :4], ref[s]["out9"][:4], atol=1e-3), (kw, s)
+            assert abs(o9[s, 4] - ref[s]["out9"][4]) <= 0.01, (kw, s)
+            assert np.abs(hm[s] - ref[s]["hist_M"]).sum() <= 4, (kw, s)
+
+
 def test_exact_peak_pruning_changes_nothing_but_time(M, oracle):
     """tune_prune skips interpolator tiles whose L1 * max|x| bound cannot beat the running peak:
     peaks must be bit-identical to the dense run, on signals that prune a lot and that prune nothing."""
