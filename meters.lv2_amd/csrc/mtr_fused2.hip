@@ -28,7 +28,7 @@
 
 #include "mtr_internal.h"
 
-typedef float v2f __attribute__ ((ext_vector_type (2)));
+#include "mtr_wave.h"
 
 __constant__ float c_fir2[3][48];   // 48-tap kernels of phases 1..3, index 0 = oldest window sample
 __constant__ float c_firs[3][24];   // mirror-symmetric form: P = (g1[i]+g1[47-i])/2, M = (g1[i]-g1[47-i])/2, Q = g2[i]
@@ -266,6 +266,17 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 		const int run0 = lane * K;
 		const int rl = min (max (len - run0, 0), K);
 		const v2f* const xr = cur + 48 + run0;
+		// Per-lane matrices of the scan's two row-broadcast steps: loaded per tile (consumed after pass 1)
+		// so they hold no VGPRs while this wave is in a FIR role; the empty asm keeps LLVM from
+		// hoisting the (loop-invariant) loads out of the tile loop.
+		const float* pw = a.scan_m + 96 + 4 * K + 4;
+		asm volatile ("" : "+s"(pw));
+		// wave-uniform tables through the constant address space: scalar loads the stores of this
+		// loop cannot clobber (see mtr_kw.hip)
+		typedef const __attribute__ ((address_space (4))) float* cfloat_p;
+		const cfloat_p CM = (cfloat_p) a.scan_m;
+		mtrw::RowMats rm;
+		rm.load (pw, lane);
 
 		// pass 1: end state of this lane's run from a zero start state.  Only the end state is
 		// needed, and it is a linear functional of the K inputs, e = sum_n A^(K-1-n) B x_n (+ the
@@ -274,52 +285,41 @@ __global__ __launch_bounds__ (TP ? 256 : 64) void k_fused2 (const mtr_fused_args
 		// skipped: nothing to its right consumes its end state.  Lane 0 adds A^K * carried state.
 		v2f z1 = 0, z2 = 0, z3 = 0, z4 = 0;
 		if (rl == K) {
-			const float* F = a.scan_m + 96;
+			const cfloat_p F = CM + 96;
 			z1 = F[4 * K + 0]; z2 = F[4 * K + 1]; z3 = F[4 * K + 2]; z4 = F[4 * K + 3];
 #pragma unroll 1
 			for (int g = 0; g < K; g += R) {          // R frames at a time: 4R coefficients in SGPRs
 #pragma unroll
 				for (int j = 0; j < R; ++j) {
 					const v2f x = xr[g + j];
-					const float* Fn = F + 4 * (g + j);
+					const cfloat_p Fn = F + 4 * (g + j);
 					z1 += Fn[0] * x; z2 += Fn[1] * x; z3 += Fn[2] * x; z4 += Fn[3] * x;
 				}
 			}
 		}
 		if (lane == 0) {
-			const float* M = a.scan_m;
+			const cfloat_p M = CM;
 			z1 += M[0] * k1 + M[1] * k2;
 			z2 += M[4] * k1 + M[5] * k2;
 			z3 += M[8] * k1 + M[9] * k2 + M[10] * k3 + M[11] * k4;
 			z4 += M[12] * k1 + M[13] * k2 + M[14] * k3 + M[15] * k4;
 		}
 
-		// wave scan (Hillis-Steele): v_l <- sum_{j<=l} (A^K)^(l-j) e_j.  A is block lower
-		// triangular (stage 1 does not see stage 2), so rows 0,1 only need columns 0,1.
-#pragma unroll
-		for (int d = 0; d < 6; ++d) {
-			const int off = 1 << d;
-			const float* M = a.scan_m + d * 16;
-			v2f w1 = shfl_up2 (z1, off), w2 = shfl_up2 (z2, off), w3 = shfl_up2 (z3, off), w4 = shfl_up2 (z4, off);
-			if (lane < off) { w1 = 0; w2 = 0; w3 = 0; w4 = 0; }
-			z1 += M[0] * w1;  z1 += M[1] * w2;
-			z2 += M[4] * w1;  z2 += M[5] * w2;
-			z3 += M[8] * w1;  z3 += M[9] * w2;  z3 += M[10] * w3; z3 += M[11] * w4;
-			z4 += M[12] * w1; z4 += M[13] * w2; z4 += M[14] * w3; z4 += M[15] * w4;
-		}
+		// wave scan on the DPP path (mtr_wave.h): z_l <- sum_{j<=l} (A^K)^(l-j) e_j
+		mtrw::scan (z1, z2, z3, z4, CM, rm);
 
 		if (warm) {
-			k1 = bcast2 (z1, 63); k2 = bcast2 (z2, 63); k3 = bcast2 (z3, 63); k4 = bcast2 (z4, 63);
+			k1 = mtrw::pick (z1, 63); k2 = mtrw::pick (z2, 63); k3 = mtrw::pick (z3, 63); k4 = mtrw::pick (z4, 63);
 		} else {
 			// pass 2: from the true start state (end state of the lane to the left), sum y^2
-			z1 = shfl_up2 (z1, 1); z2 = shfl_up2 (z2, 1); z3 = shfl_up2 (z3, 1); z4 = shfl_up2 (z4, 1);
+			z1 = mtrw::from_left (z1); z2 = mtrw::from_left (z2); z3 = mtrw::from_left (z3); z4 = mtrw::from_left (z4);
 			if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
 			v2f sj = 0;
 			for (int n = 0; n < rl; ++n) { v2f y; KW_STEP (xr[n], y); sj += y * y; }
-			const float sl = wave_sum (sj.x), sr = wave_sum (sj.y);
+			const float sl = mtrw::sum63 (sj.x), sr = mtrw::sum63 (sj.y);
 			if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = a.gain_l * sl + a.gain_r * sr;
 			const int last = (len - 1) / K;       // the lane holding the state after the last frame
-			k1 = bcast2 (z1, last); k2 = bcast2 (z2, last); k3 = bcast2 (z3, last); k4 = bcast2 (z4, last);
+			k1 = mtrw::pick (z1, last); k2 = mtrw::pick (z2, last); k3 = mtrw::pick (z3, last); k4 = mtrw::pick (z4, last);
 		}
 		// ebu_r128_proc.cc:331-334: non-finite states are dropped at block ends
 		k1 = scrub (k1); k2 = scrub (k2); k3 = scrub (k3); k4 = scrub (k4);
