@@ -43,6 +43,43 @@ def test_bitstats_bit_exact(M, oracle):
         assert r["hist"].sum() == 0 and np.all(np.isinf(r["vmin"])) and np.all(r["vmax"] == 0)
 
 
+def test_bitstats_class_switches_and_flushes(M, oracle):
+    """The positional counters of k_bitstats work inside one class of 32 exponents at a time and are
+    unloaded every 255 blocks; everything else goes through the per-exponent path.  Streams that switch
+    class, sit on class borders, are integer scaled, hold -0 / inf / nan / denormals in bulk, are not a
+    multiple of the block size and are longer than one unload interval must all stay bit-exact."""
+    T = 4 * 255 * 1024 + 4 * 1024 + 777                  # > one unload per wave, ragged tail
+    rng = np.random.default_rng(77)
+    base = sig.lcg_noise(T, 31, 1.0)[:, 0]
+    x = np.zeros((8, T), np.float32)
+    x[0] = base                                           # class 3 throughout
+    x[1] = base * np.float32(2.0 ** 15)                   # "int16 scaled": class 4 with excursions into 3
+    x[2] = base * np.float32(2.0 ** -40)                  # tiny: class 2 / 1
+    x[2, T // 2:] = base[T // 2:]                         # ... then ordinary audio: the wave must re-pick its class
+    x[3] = base
+    x[3, ::5] = -0.0
+    x[3, 7::1001] = np.inf
+    x[3, 11::1003] = -np.inf
+    x[3, 13::997] = np.nan
+    x[3, 3::17] = np.float32(1e-41)                       # denormals sprinkled over audio
+    x[4] = (rng.integers(-2 ** 23, 2 ** 23, T) * 2.0 ** -23).astype(np.float32) * np.float32(2.0 ** -28)   # straddles 2^-31
+    x[5] = np.where(np.arange(T) % 2 == 0, base, base * np.float32(2.0 ** 40))    # alternating classes 3 / 4-5
+    x[6] = sig.g5(T, 99)                                  # bit soup at length
+    x[7, 1000:] = base[1000:] * np.float32(1.9999999)     # starts with digital silence; values up to just under 2.0
+    with M.Engine(8, 48000.0, M.METER_BITSTATS, n_channels=1) as e:
+        e.process(x)
+        got = e.bitstats()
+        for s in range(8):
+            _check_bim(got, s, oracle.bitstats(x[s]))
+    # an odd stride makes every second stream unaligned for 16-byte loads
+    y = np.ascontiguousarray(x[:4, :30001])
+    with M.Engine(4, 48000.0, M.METER_BITSTATS, n_channels=1) as e:
+        e.process(y)
+        got = e.bitstats()
+        for s in range(4):
+            _check_bim(got, s, oracle.bitstats(y[s]))
+
+
 def test_sigdist_bit_exact_bins(M, oracle):
     S, T = 6, 48000
     x = np.stack([sig.lcg_noise(T, 900 + s, 2.0 ** -s)[:, 0] for s in range(S)])
