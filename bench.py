@@ -185,11 +185,14 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "k_fused2", "kernel_ms": k_ms, "gate_ms": tq["ms_gate"] / tq["calls"],
-                               "algorithmic_bytes_per_launch": S * T * BYTES_PER_FRAME,
-                               "binding_roofline": {"bound": "fp32 VALU (v_pk_fma_f32)", "achieved_tflops": valu_ops / 1e12,
-                                                    "peak_tflops": 157.3, "frac": valu_ops / 157.3e12},
-                               "note": "fp32-VALU bound, not HBM bound: the 4x interpolator alone needs 120 packed "
-                                       "VALU ops per 8-byte frame (SURVEY.md 8d: ceiling ~27% of HBM peak)"}
+                               "algorithmic_bytes_per_launch": S * T * BYTES_PER_FRAME}
+            if meters & M.METER_TRUEPEAK:
+                out["roofline"]["binding_roofline"] = {"bound": "fp32 VALU (v_pk_fma_f32)", "achieved_tflops": valu_ops / 1e12,
+                                                       "peak_tflops": 157.3, "frac": valu_ops / 157.3e12}
+                out["roofline"]["note"] = ("fp32-VALU bound, not HBM bound: the 4x interpolator alone needs 120 packed "
+                                           "VALU ops per 8-byte frame (SURVEY.md 8d: ceiling ~27% of HBM peak)")
+            elif args.layout in (0, 4):
+                out["roofline"]["kernel"] = "k_kw"              # K-weighting only: the HBM-bound kernel (mtr_kw.hip)
         elif tq["calls"] and tq["ms_bank"] > 0:
             k_ms = tq["ms_bank"] / tq["calls"]
             achieved = S * T * BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
@@ -206,8 +209,27 @@ def main():
                         float(20 * np.log10(max(res.truepeak[0], res.truepeak[1], 1e-30))),
                         "job_max_truepeak": float(agg_max[:2].max().item())}
         if world == 1 and not args.no_cpu_baseline and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
-            n = min(S, 192)
+            n = min(S, 256)
             out["cpu_baseline"] = cpu_baseline(buf[:n].cpu().numpy(), fs)
+        if world == 1 and not args.no_cpu_baseline and args.meters == "ebu+tp" and not args.prune:
+            # Reported NEXT TO the dense number, never instead of it: the same workload with exact peak
+            # pruning (bit-identical results, tests/test_gpu_layouts.py; speed depends on the programme).
+            with M.Engine(S, fs, meters, device=local, tune_run=args.run, tune_segments=args.segments,
+                          tune_layout=args.layout, tune_fir=args.fir, tune_prune=1) as pe:
+                pe.integr_start()
+                pe.process_device(buf.data_ptr(), T, T, stream)
+                torch.cuda.synchronize()
+                pe.timing_enable(True)
+                for _ in range(max(args.steps // 2, 1)):
+                    pe.process_device(buf.data_ptr(), T, T, stream)
+                torch.cuda.synchronize()
+                pq = pe.timing_query()
+                pc, pk = pe.prune_stats()
+                p_ms = pq["ms_fused"] / max(pq["calls"], 1)
+                same = bool(np.array_equal(pe.truepeak(), eng.truepeak()))
+            out["exact_pruning"] = {"kernel_ms": p_ms, "frac": S * T * BYTES_PER_FRAME / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "tiles_skipped_frac": pk / max(pc, 1), "peaks_identical_to_dense": same,
+                                    "note": "optional (tune_prune=1); not part of `value`"}
         out["programme"] = mdist.programme_summary(agg_hist, agg_max)
         if args.prune:
             c, k = eng.prune_stats()
