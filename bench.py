@@ -87,11 +87,19 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU path")
+    # MTR_BENCH_SHARED_GPU=1: every rank on GPU 0 with the gloo backend — a rehearsal of the N > 1 control
+    # flow on a one-GPU box (RCCL refuses two ranks on one device); never a measurement.
+    shared = os.environ.get("MTR_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
     fs = 48000.0
     S, T = args.streams, int(round(args.seconds * fs))
