@@ -8,6 +8,7 @@
 #ifndef MTR_LV2_MIN_H
 #define MTR_LV2_MIN_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -68,6 +69,28 @@ typedef struct { int64_t frames; LV2_Atom body; } LV2_Atom_Event;
 typedef struct { uint32_t id; uint32_t otype; } LV2_Atom_Object_Body;
 typedef struct { LV2_Atom atom; LV2_Atom_Object_Body body; } LV2_Atom_Object;
 typedef struct { uint32_t key; uint32_t context; LV2_Atom value; } LV2_Atom_Property_Body;
+typedef struct { uint32_t child_size; uint32_t child_type; } LV2_Atom_Vector_Body;
+#define LV2_ATOM__Vector    LV2_ATOM_URI "#Vector"
+#define LV2_TIME__frame     "http://lv2plug.in/ns/ext/time#frame"
+
+/* ---- state extension (LV2 "state" spec): what ebur128_save / ebur128_restore use, src/ebulv2.cc:514-566 ---- */
+#define LV2_STATE__interface "http://lv2plug.in/ns/ext/state#interface"
+typedef void* LV2_State_Handle;
+typedef enum { LV2_STATE_IS_POD = 1, LV2_STATE_IS_PORTABLE = 1 << 1, LV2_STATE_IS_NATIVE = 1 << 2 } LV2_State_Flags;
+typedef enum {
+	LV2_STATE_SUCCESS = 0, LV2_STATE_ERR_UNKNOWN = 1, LV2_STATE_ERR_BAD_TYPE = 2, LV2_STATE_ERR_BAD_FLAGS = 3,
+	LV2_STATE_ERR_NO_FEATURE = 4, LV2_STATE_ERR_NO_PROPERTY = 5, LV2_STATE_ERR_NO_SPACE = 6
+} LV2_State_Status;
+typedef LV2_State_Status (*LV2_State_Store_Function) (LV2_State_Handle handle, uint32_t key, const void* value,
+                                                      size_t size, uint32_t type, uint32_t flags);
+typedef const void* (*LV2_State_Retrieve_Function) (LV2_State_Handle handle, uint32_t key, size_t* size,
+                                                    uint32_t* type, uint32_t* flags);
+typedef struct {
+	LV2_State_Status (*save) (LV2_Handle instance, LV2_State_Store_Function store, LV2_State_Handle handle,
+	                          uint32_t flags, const LV2_Feature* const* features);
+	LV2_State_Status (*restore) (LV2_Handle instance, LV2_State_Retrieve_Function retrieve, LV2_State_Handle handle,
+	                             uint32_t flags, const LV2_Feature* const* features);
+} LV2_State_Interface;
 
 #ifdef __cplusplus
 }

@@ -6,17 +6,14 @@
  *   index  URI (prefix http://gareus.org/oss/lv2/meters#)   reference
  *   0      VUmono          src/meters.cc:298-331 (run), jmeters/vumeterdsp.cc   — CPU plumbing (config 0)
  *   1      VUstereo
- *   2      EBUr128         src/ebulv2.cc:239-498        — K-weighting + true peak on the GPU
+ *   2      EBUr128         src/ebulv2.cc (lv2_ebur128.c) — K-weighting + true peak on the GPU, full UI protocol + State
  *   3      spectr30mono    src/spectrumlv2.c:159-257    — 30-band bank on the GPU
  *   4      dBTPmono        src/meters.cc:438-508        — TruePeakdsp::process on the GPU
  *   5      dBTPstereo
  *   6      spectr30stereo
  *
  * The reference enumerates 38 plugins (src/meters.cc:745-792); LV2 hosts match by URI and stop at
- * the first NULL, so the in-scope subset is enumerated densely.  Not mirrored:
- * the EBU radar / histogram-diff messages, transport sync and LV2 State; the EBU plugin speaks the
- * subset of the atom protocol a headless host needs: meteron/meteroff, metercfg {START, PAUSE, RESET,
- * UISETTINGS} in, the `ebulevels` object out.
+ * the first NULL, so the in-scope subset is enumerated densely.
  */
 #include <math.h>
 #include <stdio.h>
@@ -25,6 +22,7 @@
 
 #include "lv2_min.h"
 #include "mtr_engine.h"
+#include "lv2_plugins.h"
 
 #define MTR_URI "http://gareus.org/oss/lv2/meters#"
 
@@ -310,238 +308,12 @@ static void spectrum_cleanup (LV2_Handle h)
 }
 
 /* ======================================================================================
- * EBUr128 (src/ebulv2.cc) with the headless subset of the atom protocol
- * ====================================================================================== */
-enum { EBU_CONTROL = 0, EBU_NOTIFY, EBU_INPUT0, EBU_OUTPUT0, EBU_INPUT1, EBU_OUTPUT1 };
-enum { CTL_START = 1, CTL_PAUSE, CTL_RESET, CTL_TRANSPORTSYNC, CTL_AUTORESET, CTL_RADARTIME, CTL_UISETTINGS };   /* src/uris.h:187-203 */
-
-typedef struct {
-	LV2_URID atom_Blank, atom_Object, atom_Int, atom_Float, atom_Bool, atom_Sequence;
-	LV2_URID mtr_ebulevels, ebu_loudnessM, ebu_maxloudnM, ebu_loudnessS, ebu_maxloudnS;
-	LV2_URID ebu_integrated, ebu_range_min, ebu_range_max, ebu_integrating, ebu_integr_time, mtr_truepeak;
-	LV2_URID mtr_cckey, mtr_ccval, mtr_control, mtr_meters_on, mtr_meters_off, mtr_meters_cfg;
-} Urids;
-
-typedef struct {
-	float* input[2];
-	float* output[2];
-	const LV2_Atom_Sequence* control;
-	LV2_Atom_Sequence* notify;
-	LV2_URID_Map* map;
-	Urids u;
-	double rate;
-	int ui_active, ebu_integrating, dbtp_enable;
-	uint32_t ui_settings;
-	uint64_t integration_time;
-	float tp_max;
-	mtr_engine* amd;
-} Ebu;
-
-static LV2_Handle ebur128_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features)
-{
-	(void) path;
-	if (strcmp (d->URI, MTR_URI "EBUr128")) return NULL;
-	Ebu* self = (Ebu*) calloc (1, sizeof (Ebu));
-	if (!self) return NULL;
-	for (int i = 0; features && features[i]; ++i)
-		if (!strcmp (features[i]->URI, LV2_URID__map)) self->map = (LV2_URID_Map*) features[i]->data;
-	if (!self->map) {                                        /* src/ebulv2.cc:140-144 */
-		fprintf (stderr, "EBUrLV2 error: Host does not support urid:map\n");
-		free (self);
-		return NULL;
-	}
-#define MAP(field, uri) self->u.field = self->map->map (self->map->handle, uri)
-	MAP (atom_Blank, LV2_ATOM__Blank); MAP (atom_Object, LV2_ATOM__Object); MAP (atom_Int, LV2_ATOM__Int);
-	MAP (atom_Float, LV2_ATOM__Float); MAP (atom_Bool, LV2_ATOM__Bool); MAP (atom_Sequence, LV2_ATOM__Sequence);
-	MAP (mtr_ebulevels, MTR_URI "ebulevels");
-	MAP (ebu_loudnessM, MTR_URI "ebu_loudnessM"); MAP (ebu_maxloudnM, MTR_URI "ebu_maxloudnM");
-	MAP (ebu_loudnessS, MTR_URI "ebu_loudnessS"); MAP (ebu_maxloudnS, MTR_URI "ebu_maxloudnS");
-	MAP (ebu_integrated, MTR_URI "ebu_integrated"); MAP (ebu_range_min, MTR_URI "ebu_range_min");
-	MAP (ebu_range_max, MTR_URI "ebu_range_max"); MAP (ebu_integrating, MTR_URI "ebu_integrating");
-	MAP (ebu_integr_time, MTR_URI "ebu_integr_time"); MAP (mtr_truepeak, MTR_URI "truepeak");
-	MAP (mtr_cckey, MTR_URI "controlkey"); MAP (mtr_ccval, MTR_URI "controlval"); MAP (mtr_control, MTR_URI "control");
-	MAP (mtr_meters_on, MTR_URI "meteron"); MAP (mtr_meters_off, MTR_URI "meteroff"); MAP (mtr_meters_cfg, MTR_URI "metercfg");
-#undef MAP
-	self->rate = rate;
-	self->ui_settings = 8;
-	self->tp_max = -INFINITY;
-	mtr_config cfg;
-	memset (&cfg, 0, sizeof (cfg));
-	cfg.struct_size = sizeof (cfg);
-	cfg.meters = MTR_METER_EBU | MTR_METER_TRUEPEAK;
-	cfg.n_streams = 1;
-	cfg.n_channels = 2;
-	cfg.sample_rate = (float) rate;
-	if (mtr_engine_create (&cfg, &self->amd) != MTR_OK) {
-		fprintf (stderr, "meters_amd: EBUr128: %s\n", mtr_last_error ());
-		free (self);
-		return NULL;
-	}
-	return self;
-}
-
-static void ebur128_connect_port (LV2_Handle h, uint32_t port, void* data)
-{
-	Ebu* self = (Ebu*) h;
-	switch (port) {
-	case EBU_INPUT0:  self->input[0] = (float*) data; break;
-	case EBU_OUTPUT0: self->output[0] = (float*) data; break;
-	case EBU_INPUT1:  self->input[1] = (float*) data; break;
-	case EBU_OUTPUT1: self->output[1] = (float*) data; break;
-	case EBU_NOTIFY:  self->notify = (LV2_Atom_Sequence*) data; break;
-	case EBU_CONTROL: self->control = (const LV2_Atom_Sequence*) data; break;
-	default: break;
-	}
-}
-
-/* ---- a forge for exactly what `ebulevels` needs ------------------------------------------- */
-typedef struct { uint8_t* buf; uint32_t cap, pos; } Forge;
-static uint32_t pad8 (uint32_t n) { return (n + 7u) & ~7u; }
-static void* forge_raw (Forge* f, uint32_t n)
-{
-	if (f->pos + pad8 (n) > f->cap) return NULL;
-	void* p = f->buf + f->pos;
-	memset (p, 0, pad8 (n));
-	f->pos += pad8 (n);
-	return p;
-}
-static void forge_prop_f32 (Forge* f, LV2_URID key, LV2_URID type, float v)
-{
-	LV2_Atom_Property_Body* p = (LV2_Atom_Property_Body*) forge_raw (f, sizeof (LV2_Atom_Property_Body) + 4);
-	if (!p) return;
-	p->key = key; p->context = 0; p->value.size = 4; p->value.type = type;
-	memcpy (p + 1, &v, 4);
-}
-static void forge_prop_i32 (Forge* f, LV2_URID key, LV2_URID type, int32_t v)
-{
-	LV2_Atom_Property_Body* p = (LV2_Atom_Property_Body*) forge_raw (f, sizeof (LV2_Atom_Property_Body) + 4);
-	if (!p) return;
-	p->key = key; p->context = 0; p->value.size = 4; p->value.type = type;
-	memcpy (p + 1, &v, 4);
-}
-
-/* value of property `key` inside an object body, or NULL */
-static const LV2_Atom* object_get (const LV2_Atom_Object* obj, LV2_URID key)
-{
-	const uint8_t* p = (const uint8_t*) (&obj->body + 1);
-	const uint8_t* end = (const uint8_t*) &obj->body + obj->atom.size;
-	while (p + sizeof (LV2_Atom_Property_Body) <= end) {
-		const LV2_Atom_Property_Body* pb = (const LV2_Atom_Property_Body*) p;
-		if (pb->key == key) return &pb->value;
-		p += pad8 ((uint32_t) sizeof (LV2_Atom_Property_Body) + pb->value.size);
-	}
-	return NULL;
-}
-
-/* src/ebulv2.cc:239-498 (the parts named in the file header) */
-static void ebur128_run (LV2_Handle h, uint32_t n_samples)
-{
-	Ebu* self = (Ebu*) h;
-	const uint32_t capacity = self->notify->atom.size;       /* the host presets the capacity, :244 */
-	Forge fg = { (uint8_t*) self->notify, capacity + (uint32_t) sizeof (LV2_Atom), 0 };
-	LV2_Atom_Sequence* seq = (LV2_Atom_Sequence*) forge_raw (&fg, sizeof (LV2_Atom_Sequence));
-	if (seq) { seq->atom.type = self->u.atom_Sequence; seq->atom.size = sizeof (LV2_Atom_Sequence_Body); }
-
-	/* incoming events, :258-331 */
-	if (self->control) {
-		const uint8_t* p = (const uint8_t*) (&self->control->body + 1);
-		const uint8_t* end = (const uint8_t*) &self->control->body + self->control->atom.size;
-		while (p + sizeof (LV2_Atom_Event) <= end) {
-			const LV2_Atom_Event* ev = (const LV2_Atom_Event*) p;
-			if (ev->body.type == self->u.atom_Blank || ev->body.type == self->u.atom_Object) {
-				const LV2_Atom_Object* obj = (const LV2_Atom_Object*) &ev->body;
-				if (obj->body.otype == self->u.mtr_meters_on) self->ui_active = 1;
-				else if (obj->body.otype == self->u.mtr_meters_off) self->ui_active = 0;
-				else if (obj->body.otype == self->u.mtr_meters_cfg) {
-					const LV2_Atom* k = object_get (obj, self->u.mtr_cckey);
-					const LV2_Atom* v = object_get (obj, self->u.mtr_ccval);
-					if (k && v) {
-						const int key = ((const LV2_Atom_Int*) k)->body;
-						const float val = ((const LV2_Atom_Float*) v)->body;
-						switch (key) {
-						case CTL_START: if (!self->ebu_integrating) { mtr_engine_integr_start (self->amd); self->ebu_integrating = 1; } break;
-						case CTL_PAUSE: if (self->ebu_integrating) { mtr_engine_integr_pause (self->amd); self->ebu_integrating = 0; } break;
-						case CTL_RESET:                                     /* ebu_reset, :47-63 */
-							mtr_engine_integr_reset (self->amd);
-							mtr_engine_truepeak_reset (self->amd);
-							self->integration_time = 0;
-							self->tp_max = -INFINITY;
-							break;
-						case CTL_UISETTINGS:
-							self->ui_settings = (uint32_t) val;
-							self->dbtp_enable = (self->ui_settings & 64) ? 1 : 0;
-							break;
-						default: break;
-						}
-					} else {
-						fprintf (stderr, "MTRlv2: Malformed ctrl message has no key or value.\n");
-					}
-				}
-			}
-			p += pad8 ((uint32_t) sizeof (LV2_Atom_Event) + ev->body.size);
-		}
-	}
-
-	/* audio, :340-347 */
-	const float* in[2] = { self->input[0], self->input[1] };
-	if (n_samples > 0) mtr_engine_process_planar_host (self->amd, in, n_samples);
-	mtr_stream_result r;
-	memset (&r, 0, sizeof (r));
-	mtr_engine_results (self->amd, 0, 1, &r);
-
-	if (self->dbtp_enable) {                                  /* :360-367 */
-		const float tp0 = r.truepeak_call[0], tp1 = r.truepeak_call[1];
-		const float tpm = tp0 > tp1 ? tp0 : tp1;
-		const float tp = tpm == 0 ? -INFINITY : (float) (20.0 * log10f (tpm));
-		if (tp > self->tp_max) self->tp_max = tp;
-	} else {
-		self->tp_max = -INFINITY;
-	}
-	if (self->ebu_integrating) self->integration_time += n_samples;
-
-	/* `ebulevels` to the UI, :465-482 */
-	if (self->ui_active && seq) {
-		const uint32_t ev_pos = fg.pos;
-		LV2_Atom_Event* ev = (LV2_Atom_Event*) forge_raw (&fg, sizeof (LV2_Atom_Event) + sizeof (LV2_Atom_Object_Body));
-		if (ev) {
-			ev->frames = 0;
-			ev->body.type = self->u.atom_Object;
-			LV2_Atom_Object_Body* ob = (LV2_Atom_Object_Body*) (ev + 1);
-			ob->id = 1; ob->otype = self->u.mtr_ebulevels;
-			const uint32_t body0 = fg.pos - (uint32_t) sizeof (LV2_Atom_Object_Body);
-			forge_prop_f32 (&fg, self->u.ebu_loudnessM, self->u.atom_Float, r.loudness_M);
-			forge_prop_f32 (&fg, self->u.ebu_maxloudnM, self->u.atom_Float, r.maxloudn_M);
-			forge_prop_f32 (&fg, self->u.ebu_loudnessS, self->u.atom_Float, r.loudness_S);
-			forge_prop_f32 (&fg, self->u.ebu_maxloudnS, self->u.atom_Float, r.maxloudn_S);
-			forge_prop_f32 (&fg, self->u.ebu_integrated, self->u.atom_Float, r.integrated);
-			forge_prop_f32 (&fg, self->u.ebu_range_min, self->u.atom_Float, r.range_min);
-			forge_prop_f32 (&fg, self->u.ebu_range_max, self->u.atom_Float, r.range_max);
-			forge_prop_f32 (&fg, self->u.mtr_truepeak, self->u.atom_Float, self->tp_max);
-			forge_prop_i32 (&fg, self->u.ebu_integrating, self->u.atom_Bool, self->ebu_integrating);
-			forge_prop_f32 (&fg, self->u.ebu_integr_time, self->u.atom_Float, (float) (self->integration_time / self->rate));
-			ev->body.size = fg.pos - body0;
-			seq->atom.size += fg.pos - ev_pos;
-		}
-	}
-
-	for (int c = 0; c < 2; ++c)
-		if (self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
-}
-
-static void ebur128_cleanup (LV2_Handle h)
-{
-	Ebu* self = (Ebu*) h;
-	if (self->amd) mtr_engine_destroy (self->amd);
-	free (self);
-}
-
-/* ======================================================================================
  * descriptors (8 positional members, src/meters.cc:683-693)
  * ====================================================================================== */
 static const LV2_Descriptor descriptors[] = {
 	{ MTR_URI "VUmono",         meter_instantiate,    meter_connect_port,    NULL, vu_run,       NULL, meter_cleanup,    no_extension },
 	{ MTR_URI "VUstereo",       meter_instantiate,    meter_connect_port,    NULL, vu_run,       NULL, meter_cleanup,    no_extension },
-	{ MTR_URI "EBUr128",        ebur128_instantiate,  ebur128_connect_port,  NULL, ebur128_run,  NULL, ebur128_cleanup,  no_extension },
+	{ MTR_URI "EBUr128",        ebur128_instantiate,  ebur128_connect_port,  NULL, ebur128_run,  NULL, ebur128_cleanup,  ebur128_extension_data },
 	{ MTR_URI "spectr30mono",   spectrum_instantiate, spectrum_connect_port, NULL, spectrum_run, NULL, spectrum_cleanup, no_extension },
 	{ MTR_URI "dBTPmono",       meter_instantiate,    meter_connect_port,    NULL, dbtp_run,     NULL, meter_cleanup,    no_extension },
 	{ MTR_URI "dBTPstereo",     meter_instantiate,    meter_connect_port,    NULL, dbtp_run,     NULL, meter_cleanup,    no_extension },

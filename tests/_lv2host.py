@@ -96,6 +96,47 @@ class Instance:
             self.desc.cleanup(self.handle)
             self.handle = None
 
+    # ---- LV2 State through extension_data (state#interface: {save, restore}) ----
+    def _state_iface(self):
+        p = self.desc.extension_data(b"http://lv2plug.in/ns/ext/state#interface")
+        return C.cast(p, C.POINTER(_StateIface)).contents if p else None
+
+    def state_save(self):
+        """-> {key_urid: (bytes, type_urid, flags)} as the plugin hands it to the host's store()."""
+        iface, kept = self._state_iface(), {}
+
+        def store(handle, key, value, size, typ, flags):
+            kept[key] = (C.string_at(value, size), typ, flags)
+            return 0
+        cb = _STORE(store)
+        assert iface.save(self.handle, cb, None, 0, None) == 0
+        return kept
+
+    def state_restore(self, kept):
+        iface, hold = self._state_iface(), []
+
+        def retrieve(handle, key, size, typ, flags):
+            if key not in kept:
+                return None
+            raw, t, fl = kept[key]
+            buf = C.create_string_buffer(raw, len(raw))
+            hold.append(buf)
+            size[0], typ[0], flags[0] = len(raw), t, fl
+            return C.addressof(buf)
+        cb = _RETRIEVE(retrieve)
+        assert iface.restore(self.handle, cb, None, 0, None) == 0
+
+
+_STORE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32)
+_RETRIEVE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
+                        C.POINTER(C.c_uint32))
+_SAVE = C.CFUNCTYPE(C.c_int, C.c_void_p, _STORE, C.c_void_p, C.c_uint32, C.c_void_p)
+_RESTORE = C.CFUNCTYPE(C.c_int, C.c_void_p, _RETRIEVE, C.c_void_p, C.c_uint32, C.c_void_p)
+
+
+class _StateIface(C.Structure):
+    _fields_ = [("save", _SAVE), ("restore", _RESTORE)]
+
 
 # ---- atoms ------------------------------------------------------------------------------------
 

@@ -129,7 +129,64 @@ class MoHist(C.Structure):
     _fields_ = [("histc", C.c_int * HIST_LEN), ("count", C.c_int), ("error", C.c_int)]
 
 
+class MoEbu(C.Structure):
+    """mo_ebu of oracle/mtr_oracle.h (MO_MAXCH = 5), for block-by-block use."""
+    _fields_ = [("integr", C.c_int), ("nchan", C.c_int), ("fsamp", C.c_float), ("fragm", C.c_int), ("frcnt", C.c_int),
+                ("frpwr", C.c_float), ("power", C.c_float * 64), ("wrind", C.c_int), ("div1", C.c_int), ("div2", C.c_int),
+                ("loudness_M", C.c_float), ("maxloudn_M", C.c_float), ("loudness_S", C.c_float), ("maxloudn_S", C.c_float),
+                ("integrated", C.c_float), ("integ_thr", C.c_float), ("range_min", C.c_float), ("range_max", C.c_float),
+                ("range_thr", C.c_float), ("k", MoKw), ("z", (C.c_float * 4) * 5), ("hist_M", MoHist), ("hist_S", MoHist)]
+
+
+class EbuStream:
+    """One Ebu_r128_proc + two TruePeakdsp fed block by block, with the integration controls — what an
+    EBUr128 plugin instance holds (src/ebulv2.cc:189-196)."""
+
+    def __init__(self, lib, fs):
+        self.lib, self.e, self.t = lib, MoEbu(), (MoTp(), MoTp())
+        lib.mo_ebu_init.argtypes = [C.POINTER(MoEbu), C.c_int, C.c_float]
+        lib.mo_ebu_process.argtypes = [C.POINTER(MoEbu), C.c_int, C.POINTER(C.c_void_p)]
+        for f in ("mo_ebu_integr_start", "mo_ebu_integr_pause", "mo_ebu_integr_reset"):
+            getattr(lib, f).argtypes = [C.POINTER(MoEbu)]
+        lib.mo_tp_init.argtypes = [C.POINTER(MoTp), C.c_float]
+        lib.mo_tp_process_max.argtypes = [C.POINTER(MoTp), _f32p, C.c_int]
+        lib.mo_tp_read.argtypes = [C.POINTER(MoTp)]
+        lib.mo_tp_read.restype = C.c_float
+        lib.mo_ebu_init(C.byref(self.e), 2, fs)
+        for t in self.t:
+            lib.mo_tp_init(C.byref(t), fs)
+
+    def start(self):
+        self.lib.mo_ebu_integr_start(C.byref(self.e))
+
+    def pause(self):
+        self.lib.mo_ebu_integr_pause(C.byref(self.e))
+
+    def reset(self):
+        self.lib.mo_ebu_integr_reset(C.byref(self.e))
+
+    def process(self, left, right, with_tp=True):
+        """-> (out9, hist_M, hist_S, counts, (tp_l, tp_r) of this block or None)"""
+        left = np.ascontiguousarray(left, np.float32)
+        right = np.ascontiguousarray(right, np.float32)
+        ptrs = (C.c_void_p * 2)(left.ctypes.data, right.ctypes.data)
+        self.lib.mo_ebu_process(C.byref(self.e), left.size, ptrs)
+        tp = None
+        if with_tp:
+            self.lib.mo_tp_process_max(C.byref(self.t[0]), left, left.size)
+            self.lib.mo_tp_process_max(C.byref(self.t[1]), right, right.size)
+            tp = (self.lib.mo_tp_read(C.byref(self.t[0])), self.lib.mo_tp_read(C.byref(self.t[1])))
+        e = self.e
+        out9 = np.array([e.loudness_M, e.maxloudn_M, e.loudness_S, e.maxloudn_S, e.integrated, e.integ_thr,
+                         e.range_min, e.range_max, e.range_thr], np.float32)
+        return (out9, np.array(e.hist_M.histc, np.int32), np.array(e.hist_S.histc, np.int32),
+                (e.hist_M.count, e.hist_S.count), tp)
+
+
 class Oracle(_Batch):
+    def ebu_stream(self, fs=48000.0):
+        return EbuStream(self.lib, fs)
+
     def __init__(self):
         lib = C.CDLL(build_oracle())
         super().__init__(lib, "mo_")

@@ -180,49 +180,4 @@ def test_spectr30_stereo(host, oracle):
     inst.cleanup()
 
 
-@pytest.mark.gpu
-def test_ebur128_headless_atom_protocol(host, oracle):
-    import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-    from make_golden import tri_noise
-    assert not Instance(host, "EBUr128", with_urid_map=False).ok()
-    x = tri_noise(48000 * 12, 777, 0.25)
-    inst = Instance(host, "EBUr128")
-    assert inst.ok()
-    notify = notify_buffer()
-    inst.connect(1, notify)
-    K = MTR_URI
-    start = forge_sequence(host, [
-        forge_object(host, K + "meteron", []),
-        forge_object(host, K + "metercfg", [(K + "controlkey", "i", 7), (K + "controlval", "f", 8.0 + 64.0)]),  # UISETTINGS: dBTP on
-        forge_object(host, K + "metercfg", [(K + "controlkey", "i", 1), (K + "controlval", "f", 0.0)]),         # START
-    ])
-    empty = forge_sequence(host, [])
-    msgs = None
-    for i, p in enumerate(range(0, x.shape[0], 1024)):
-        bl, br = x[p:p + 1024, 0].copy(), x[p:p + 1024, 1].copy()
-        inst.connect(0, start if i == 0 else empty)
-        for port, arr in ((2, bl), (3, bl), (4, br), (5, br)):
-            inst.connect(port, arr)
-        arm_notify(notify)
-        inst.run(bl.size)
-        msgs = parse_sequence(host, notify)
-        assert len(msgs) == 1 and msgs[0][0] == K + "ebulevels" and len(msgs[0][1]) == 10
-    lv = msgs[0][1]
-    o = oracle.ebu(x, 48000.0, 1024)["out9"]
-    assert abs(lv[K + "ebu_loudnessM"] - o[0]) < 1e-3 and abs(lv[K + "ebu_maxloudnM"] - o[1]) < 1e-3
-    assert abs(lv[K + "ebu_loudnessS"] - o[2]) < 1e-3 and abs(lv[K + "ebu_maxloudnS"] - o[3]) < 1e-3
-    assert abs(lv[K + "ebu_integrated"] - o[4]) <= 0.01
-    assert abs(lv[K + "ebu_range_min"] - o[6]) <= 0.1001 and abs(lv[K + "ebu_range_max"] - o[7]) <= 0.1001
-    assert lv[K + "ebu_integrating"] == 1 and abs(lv[K + "ebu_integr_time"] - 12.0) < 1e-3
-    tp = oracle.tp(x, 48000.0, 1024)
-    assert abs(lv[K + "truepeak"] - 20 * np.log10(tp.max())) < 1e-3
-    # PAUSE then RESET
-    inst.connect(0, forge_sequence(host, [
-        forge_object(host, K + "metercfg", [(K + "controlkey", "i", 2), (K + "controlval", "f", 0.0)]),
-        forge_object(host, K + "metercfg", [(K + "controlkey", "i", 3), (K + "controlval", "f", 0.0)])]))
-    arm_notify(notify)
-    inst.run(0)
-    lv = parse_sequence(host, notify)[0][1]
-    assert lv[K + "ebu_integrating"] == 0 and lv[K + "ebu_integrated"] == -200.0 and lv[K + "ebu_integr_time"] == 0.0
-    inst.cleanup()
+# The EBUr128 plugin has its own file: tests/test_lv2_ebur128.py (the whole UI protocol, message by message).
