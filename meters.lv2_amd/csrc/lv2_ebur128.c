@@ -15,9 +15,7 @@
  *        rdr_histogram {M, S}                 new histogram maxima
  *        ebulevels {10 values}                every cycle while the UI is attached
  *
- * No LV2 SDK in this image: the atom layouts come from include/lv2_min.h and the little forge below
- * writes exactly what lv2_atom_forge_* would (8-byte padded bodies, object = {id 1, otype} + properties
- * {key, context 0, value atom}, events at frame 0 appended to the notify sequence).
+ * No LV2 SDK in this image: the atom layouts come from include/lv2_min.h, the writer is lv2_forge.h.
  */
 #include <math.h>
 #include <stdio.h>
@@ -26,27 +24,20 @@
 
 #include "lv2_min.h"
 #include "mtr_engine.h"
+#include "lv2_forge.h"
 #include "lv2_plugins.h"
 
-#define MTR_URI "http://gareus.org/oss/lv2/meters#"
 #define HIST_LEN 751                                         /* src/uris.h:45 */
 
 enum { EBU_CONTROL = 0, EBU_NOTIFY, EBU_INPUT0, EBU_OUTPUT0, EBU_INPUT1, EBU_OUTPUT1 };
-/* numeric keys of the control messages, src/uris.h:187-203 */
-enum { KEY_INVALID = 0, CTL_START, CTL_PAUSE, CTL_RESET, CTL_TRANSPORTSYNC, CTL_AUTORESET, CTL_RADARTIME, CTL_UISETTINGS,
-       CTL_LV2_RADARTIME, CTL_LV2_FTM, CTL_LV2_RESETRADAR, CTL_LV2_RESYNCDONE };
 
 typedef struct {
-	LV2_URID atom_Blank, atom_Object, atom_Int, atom_Float, atom_Bool, atom_Sequence;
-	LV2_URID time_Position, time_speed;
+	ForgeUrids f;
 	LV2_URID mtr_ebulevels, ebu_loudnessM, ebu_maxloudnM, ebu_loudnessS, ebu_maxloudnS;
 	LV2_URID ebu_integrated, ebu_range_min, ebu_range_max, ebu_integrating, ebu_integr_time, mtr_truepeak;
 	LV2_URID ebu_state;
 	LV2_URID rdr_histogram, rdr_histpoint, rdr_radarpoint, rdr_pointpos, rdr_pos_cur, rdr_pos_max;
-	LV2_URID mtr_cckey, mtr_ccval, mtr_control, mtr_meters_on, mtr_meters_off, mtr_meters_cfg;
 } Urids;
-
-typedef struct { uint8_t* buf; uint32_t cap, pos; LV2_Atom_Sequence* seq; const Urids* u; } Forge;
 
 typedef struct {
 	float* input[2];
@@ -76,86 +67,6 @@ typedef struct {
 	mtr_engine* amd;
 	int32_t devM[HIST_LEN], devS[HIST_LEN];                  /* the engine's histograms, fetched per cycle */
 } Ebu;
-
-/* ---- forge ------------------------------------------------------------------------------------ */
-static uint32_t pad8 (uint32_t n) { return (n + 7u) & ~7u; }
-
-static void* forge_raw (Forge* f, uint32_t n)
-{
-	if (f->pos + pad8 (n) > f->cap) return NULL;
-	void* p = f->buf + f->pos;
-	memset (p, 0, pad8 (n));
-	f->pos += pad8 (n);
-	return p;
-}
-
-static void forge_begin (Forge* f, LV2_Atom_Sequence* notify, const Urids* u)
-{
-	/* the host presets notify->atom.size to the capacity of the buffer behind it (src/ebulv2.cc:244) */
-	f->buf = (uint8_t*) notify;
-	f->cap = notify->atom.size + (uint32_t) sizeof (LV2_Atom);
-	f->pos = 0;
-	f->u = u;
-	f->seq = (LV2_Atom_Sequence*) forge_raw (f, sizeof (LV2_Atom_Sequence));
-	if (f->seq) { f->seq->atom.type = u->atom_Sequence; f->seq->atom.size = sizeof (LV2_Atom_Sequence_Body); }
-}
-
-typedef struct { LV2_Atom_Event* ev; uint32_t ev_pos, body0; } ObjFrame;
-
-/* lv2_atom_forge_frame_time (0) + lv2_atom_forge_object (id 1, otype) */
-static int obj_begin (Forge* f, ObjFrame* fr, LV2_URID otype)
-{
-	if (!f->seq) return 0;
-	fr->ev_pos = f->pos;
-	fr->ev = (LV2_Atom_Event*) forge_raw (f, sizeof (LV2_Atom_Event) + sizeof (LV2_Atom_Object_Body));
-	if (!fr->ev) return 0;
-	fr->ev->frames = 0;
-	fr->ev->body.type = f->u->atom_Object;
-	LV2_Atom_Object_Body* ob = (LV2_Atom_Object_Body*) (fr->ev + 1);
-	ob->id = 1; ob->otype = otype;
-	fr->body0 = f->pos - (uint32_t) sizeof (LV2_Atom_Object_Body);
-	return 1;
-}
-static void prop4 (Forge* f, LV2_URID key, LV2_URID type, const void* v)
-{
-	LV2_Atom_Property_Body* p = (LV2_Atom_Property_Body*) forge_raw (f, sizeof (LV2_Atom_Property_Body) + 4);
-	if (!p) return;
-	p->key = key; p->context = 0; p->value.size = 4; p->value.type = type;
-	memcpy (p + 1, v, 4);
-}
-static void prop_f (Forge* f, LV2_URID key, float v)   { prop4 (f, key, f->u->atom_Float, &v); }
-static void prop_i (Forge* f, LV2_URID key, int32_t v) { prop4 (f, key, f->u->atom_Int, &v); }
-static void prop_b (Forge* f, LV2_URID key, int32_t v) { prop4 (f, key, f->u->atom_Bool, &v); }
-static void obj_end (Forge* f, ObjFrame* fr)
-{
-	fr->ev->body.size = f->pos - fr->body0;
-	f->seq->atom.size += f->pos - fr->ev_pos;
-}
-/* bytes of the notify atom in use, what the reference reads back as self->notify->atom.size */
-static uint32_t forge_used (const Forge* f) { return f->seq ? f->seq->atom.size : 0; }
-
-/* forge_kvcontrolmessage, src/uris.h:280-296 */
-static void kv_message (Forge* f, int key, float value)
-{
-	ObjFrame fr;
-	if (!obj_begin (f, &fr, f->u->mtr_control)) return;
-	prop_i (f, f->u->mtr_cckey, key);
-	prop_f (f, f->u->mtr_ccval, value);
-	obj_end (f, &fr);
-}
-
-/* value of property `key` inside an object body, or NULL (lv2_atom_object_get for one key) */
-static const LV2_Atom* object_get (const LV2_Atom_Object* obj, LV2_URID key)
-{
-	const uint8_t* p = (const uint8_t*) (&obj->body + 1);
-	const uint8_t* end = (const uint8_t*) &obj->body + obj->atom.size;
-	while (p + sizeof (LV2_Atom_Property_Body) <= end) {
-		const LV2_Atom_Property_Body* pb = (const LV2_Atom_Property_Body*) p;
-		if (pb->key == key) return &pb->value;
-		p += pad8 ((uint32_t) sizeof (LV2_Atom_Property_Body) + pb->value.size);
-	}
-	return NULL;
-}
 
 /* ---- helpers of the reference, src/ebulv2.cc:44-112 ---------------------------------------------- */
 static void ebu_reset (Ebu* self)
@@ -196,8 +107,8 @@ static void ebu_set_radarspeed (Ebu* self, float seconds)
 
 static void update_position (Ebu* self, const LV2_Atom_Object* obj)
 {
-	const LV2_Atom* speed = object_get (obj, self->u.time_speed);
-	if (speed && speed->type == self->u.atom_Float) {
+	const LV2_Atom* speed = object_get (obj, self->u.f.time_speed);
+	if (speed && speed->type == self->u.f.atom_Float) {
 		const float ts = ((const LV2_Atom_Float*) speed)->body;
 		if (ts != 0 && !self->tranport_rolling) { if (self->follow_transport_mode & 1) ebu_integrate (self, 1); }
 		if (ts == 0 && self->tranport_rolling)  { if (self->follow_transport_mode & 1) ebu_integrate (self, 0); }
@@ -220,9 +131,7 @@ LV2_Handle ebur128_instantiate (const LV2_Descriptor* d, double rate, const char
 		return NULL;
 	}
 #define MAP(field, uri) self->u.field = self->map->map (self->map->handle, uri)
-	MAP (atom_Blank, LV2_ATOM__Blank); MAP (atom_Object, LV2_ATOM__Object); MAP (atom_Int, LV2_ATOM__Int);
-	MAP (atom_Float, LV2_ATOM__Float); MAP (atom_Bool, LV2_ATOM__Bool); MAP (atom_Sequence, LV2_ATOM__Sequence);
-	MAP (time_Position, LV2_TIME__Position); MAP (time_speed, LV2_TIME__speed);
+	forge_map_urids (self->map, &self->u.f);
 	MAP (mtr_ebulevels, MTR_URI "ebulevels");
 	MAP (ebu_loudnessM, MTR_URI "ebu_loudnessM"); MAP (ebu_maxloudnM, MTR_URI "ebu_maxloudnM");
 	MAP (ebu_loudnessS, MTR_URI "ebu_loudnessS"); MAP (ebu_maxloudnS, MTR_URI "ebu_maxloudnS");
@@ -233,8 +142,6 @@ LV2_Handle ebur128_instantiate (const LV2_Descriptor* d, double rate, const char
 	MAP (rdr_histogram, MTR_URI "rdr_histogram"); MAP (rdr_histpoint, MTR_URI "rdr_histpoint");
 	MAP (rdr_radarpoint, MTR_URI "rdr_radarpoint"); MAP (rdr_pointpos, MTR_URI "rdr_pointpos");
 	MAP (rdr_pos_cur, MTR_URI "rdr_pos_cur"); MAP (rdr_pos_max, MTR_URI "rdr_pos_max");
-	MAP (mtr_cckey, MTR_URI "controlkey"); MAP (mtr_ccval, MTR_URI "controlval"); MAP (mtr_control, MTR_URI "control");
-	MAP (mtr_meters_on, MTR_URI "meteron"); MAP (mtr_meters_off, MTR_URI "meteroff"); MAP (mtr_meters_cfg, MTR_URI "metercfg");
 #undef MAP
 	self->rate = rate;
 	self->radar_pos_max = 360;
@@ -294,7 +201,7 @@ void ebur128_run (LV2_Handle h, uint32_t n_samples)
 	Ebu* self = (Ebu*) h;
 	const uint32_t capacity = self->notify->atom.size;
 	Forge* const fg = &self->fg;
-	forge_begin (fg, self->notify, &self->u);
+	forge_begin (fg, self->notify, &self->u.f);
 
 	if (self->send_state_to_ui && self->ui_active) {          /* :248-255 */
 		self->send_state_to_ui = 0;
@@ -305,64 +212,51 @@ void ebur128_run (LV2_Handle h, uint32_t n_samples)
 
 	/* incoming events, :257-331 */
 	if (self->control) {
-		const uint8_t* p = (const uint8_t*) (&self->control->body + 1);
-		const uint8_t* end = (const uint8_t*) &self->control->body + self->control->atom.size;
-		while (p + sizeof (LV2_Atom_Event) <= end) {
-			const LV2_Atom_Event* ev = (const LV2_Atom_Event*) p;
-			if (ev->body.type == self->u.atom_Blank || ev->body.type == self->u.atom_Object) {
-				const LV2_Atom_Object* obj = (const LV2_Atom_Object*) &ev->body;
-				if (obj->body.otype == self->u.time_Position) {
-					update_position (self, obj);
-				} else if (obj->body.otype == self->u.mtr_meters_on) {
-					self->ui_active = 1;
-					self->send_state_to_ui = 1;
-					self->radar_resync = 0;
-					memset (self->histM, 0, sizeof (self->histM));      /* resync histogram */
-					memset (self->histS, 0, sizeof (self->histS));
-					self->hist_maxM = 0;
-					self->hist_maxS = 0;
-				} else if (obj->body.otype == self->u.mtr_meters_off) {
-					self->ui_active = 0;
-				} else if (obj->body.otype == self->u.mtr_meters_cfg) {
-					const LV2_Atom* k = object_get (obj, self->u.mtr_cckey);
-					const LV2_Atom* v = object_get (obj, self->u.mtr_ccval);
-					if (!k || !v) {
-						fprintf (stderr, "MTRlv2: Malformed ctrl message has no key or value.\n");
+		FORGE_FOREACH_OBJECT (self->control, &self->u.f, obj) {
+			if (obj->body.otype == self->u.f.time_Position) {
+				update_position (self, obj);
+			} else if (obj->body.otype == self->u.f.mtr_meters_on) {
+				self->ui_active = 1;
+				self->send_state_to_ui = 1;
+				self->radar_resync = 0;
+				memset (self->histM, 0, sizeof (self->histM));          /* resync histogram */
+				memset (self->histS, 0, sizeof (self->histS));
+				self->hist_maxM = 0;
+				self->hist_maxS = 0;
+			} else if (obj->body.otype == self->u.f.mtr_meters_off) {
+				self->ui_active = 0;
+			} else if (obj->body.otype == self->u.f.mtr_meters_cfg) {
+				int key; float val;
+				get_cc_key_value (&self->u.f, obj, &key, &val);
+				switch (key) {
+				case CTL_START: ebu_integrate (self, 1); break;
+				case CTL_PAUSE: ebu_integrate (self, 0); break;
+				case CTL_RESET: ebu_reset (self); break;
+				case CTL_TRANSPORTSYNC:
+					if (val == 1) {
+						self->follow_transport_mode |= 1;
+						if (self->tranport_rolling != self->ebu_integrating) ebu_integrate (self, self->tranport_rolling);
 					} else {
-						const int key = ((const LV2_Atom_Int*) k)->body;
-						const float val = ((const LV2_Atom_Float*) v)->body;
-						switch (key) {
-						case CTL_START: ebu_integrate (self, 1); break;
-						case CTL_PAUSE: ebu_integrate (self, 0); break;
-						case CTL_RESET: ebu_reset (self); break;
-						case CTL_TRANSPORTSYNC:
-							if (val == 1) {
-								self->follow_transport_mode |= 1;
-								if (self->tranport_rolling != self->ebu_integrating) ebu_integrate (self, self->tranport_rolling);
-							} else {
-								self->follow_transport_mode &= ~1;
-							}
-							break;
-						case CTL_AUTORESET:
-							if (val == 1) self->follow_transport_mode |= 2; else self->follow_transport_mode &= ~2;
-							break;
-						case CTL_RADARTIME:
-							if (val >= 30 && val <= 600) {
-								ebu_set_radarspeed (self, val);
-								if (self->radar_spd_max < 2 * n_samples) self->radar_spd_max = 2 * n_samples;
-							}
-							kv_message (fg, CTL_LV2_RADARTIME, (float) (self->radar_pos_max * self->radar_spd_max / self->rate));
-							break;
-						case CTL_UISETTINGS:
-							self->ui_settings = (uint32_t) val;
-							self->dbtp_enable = (self->ui_settings & 64) ? 1 : 0;
-							break;
-						default: break;
-						}
+						self->follow_transport_mode &= ~1;
 					}
+					break;
+				case CTL_AUTORESET:
+					if (val == 1) self->follow_transport_mode |= 2; else self->follow_transport_mode &= ~2;
+					break;
+				case CTL_RADARTIME:
+					if (val >= 30 && val <= 600) {
+						ebu_set_radarspeed (self, val);
+						if (self->radar_spd_max < 2 * n_samples) self->radar_spd_max = 2 * n_samples;
+					}
+					kv_message (fg, CTL_LV2_RADARTIME, (float) (self->radar_pos_max * self->radar_spd_max / self->rate));
+					break;
+				case CTL_UISETTINGS:
+					self->ui_settings = (uint32_t) val;
+					self->dbtp_enable = (self->ui_settings & 64) ? 1 : 0;
+					break;
+				default: break;
 				}
 			}
-			p += pad8 ((uint32_t) sizeof (LV2_Atom_Event) + ev->body.size);
 		}
 	}
 
@@ -483,7 +377,7 @@ static LV2_State_Status ebur128_save (LV2_Handle h, LV2_State_Store_Function sto
 	uint32_t cfg = self->ui_settings;
 	cfg |= (uint32_t) self->follow_transport_mode << 8;
 	cfg |= self->radar_spd_max << 16;
-	store (handle, self->u.ebu_state, (void*) &cfg, sizeof (uint32_t), self->u.atom_Int, LV2_STATE_IS_POD | LV2_STATE_IS_PORTABLE);
+	store (handle, self->u.ebu_state, (void*) &cfg, sizeof (uint32_t), self->u.f.atom_Int, LV2_STATE_IS_POD | LV2_STATE_IS_PORTABLE);
 	return LV2_STATE_SUCCESS;
 }
 
@@ -495,7 +389,7 @@ static LV2_State_Status ebur128_restore (LV2_Handle h, LV2_State_Retrieve_Functi
 	size_t size;
 	uint32_t type, valflags;
 	const void* value = retrieve (handle, self->u.ebu_state, &size, &type, &valflags);
-	if (value && size == sizeof (uint32_t) && type == self->u.atom_Int) {
+	if (value && size == sizeof (uint32_t) && type == self->u.f.atom_Int) {
 		const uint32_t cfg = *((const uint32_t*) value);
 		self->ui_settings = cfg & 0xff;
 		self->follow_transport_mode = (cfg >> 8) & 0x3;

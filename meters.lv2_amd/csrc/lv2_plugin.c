@@ -11,6 +11,8 @@
  *   4      dBTPmono        src/meters.cc:438-508        — TruePeakdsp::process on the GPU
  *   5      dBTPstereo
  *   6      spectr30stereo
+ *   7      SigDistHist     src/sigdistlv2.c (lv2_intstat.c) — signal-distribution histogram on the GPU, UI protocol + State
+ *   8      bitmeter        src/bitmeter.c (lv2_intstat.c)   — IEEE-754 bit statistics on the GPU, UI protocol + State
  *
  * The reference enumerates 38 plugins (src/meters.cc:745-792); LV2 hosts match by URI and stop at
  * the first NULL, so the in-scope subset is enumerated densely.
@@ -318,6 +320,8 @@ static const LV2_Descriptor descriptors[] = {
 	{ MTR_URI "dBTPmono",       meter_instantiate,    meter_connect_port,    NULL, dbtp_run,     NULL, meter_cleanup,    no_extension },
 	{ MTR_URI "dBTPstereo",     meter_instantiate,    meter_connect_port,    NULL, dbtp_run,     NULL, meter_cleanup,    no_extension },
 	{ MTR_URI "spectr30stereo", spectrum_instantiate, spectrum_connect_port, NULL, spectrum_run, NULL, spectrum_cleanup, no_extension },
+	{ MTR_URI "SigDistHist",    sdh_instantiate,      intstat_connect_port,  NULL, sdh_run,      NULL, intstat_cleanup,  sdh_extension_data },
+	{ MTR_URI "bitmeter",       bim_instantiate,      intstat_connect_port,  NULL, bim_run,      NULL, intstat_cleanup,  bim_extension_data },
 };
 
 LV2_SYMBOL_EXPORT const LV2_Descriptor* lv2_descriptor (uint32_t index)

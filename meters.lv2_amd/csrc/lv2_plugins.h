@@ -12,4 +12,14 @@ void        ebur128_run (LV2_Handle h, uint32_t n_samples);
 void        ebur128_cleanup (LV2_Handle h);
 const void* ebur128_extension_data (const char* uri);
 
+/* lv2_intstat.c — src/bitmeter.c, src/sigdistlv2.c */
+LV2_Handle  bim_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features);
+void        bim_run (LV2_Handle h, uint32_t n_samples);
+const void* bim_extension_data (const char* uri);
+LV2_Handle  sdh_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features);
+void        sdh_run (LV2_Handle h, uint32_t n_samples);
+const void* sdh_extension_data (const char* uri);
+void        intstat_connect_port (LV2_Handle h, uint32_t port, void* data);
+void        intstat_cleanup (LV2_Handle h);
+
 #endif

@@ -190,6 +190,13 @@ def parse_sequence(host, buf):
                 vt = rev.get(vtype, "")
                 if vt.endswith("#Float"):
                     val = struct.unpack_from("<f", raw, q + 16)[0]
+                elif vt.endswith("#Double"):
+                    val = struct.unpack_from("<d", raw, q + 16)[0]
+                elif vt.endswith("#Long"):
+                    val = struct.unpack_from("<q", raw, q + 16)[0]
+                elif vt.endswith("#Vector"):
+                    csize, _ctype = struct.unpack_from("<II", raw, q + 16)
+                    val = np.frombuffer(raw, np.int32, (vsize - 8) // csize, q + 24).copy()
                 else:
                     val = struct.unpack_from("<i", raw, q + 16)[0]
                 props[rev.get(key, key)] = val

@@ -12,12 +12,16 @@ def test_ttl_matches_the_plugin_port_maps(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_ttl.py"), str(tmp_path)])
     man = open(tmp_path / "manifest.ttl").read()
     ttl = open(tmp_path / "meters_amd.ttl").read()
-    plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo"]
+    plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
+             "SigDistHist", "bitmeter"]
     for p in plugs:
         assert f"mtr:{p}\n" in man and "lv2:binary <meters_amd.so>" in man
     blocks = {p: ttl.split(f"mtr:{p}\n")[1].split("\n\t.\n")[0] for p in plugs}
     want = {"VUmono": 4, "VUstereo": 7, "EBUr128": 6, "spectr30mono": 66, "dBTPmono": 5, "dBTPstereo": 9,
-            "spectr30stereo": 68}
+            "spectr30stereo": 68, "SigDistHist": 4, "bitmeter": 4}
+    for p in ("SigDistHist", "bitmeter"):
+        assert re.findall(r'lv2:symbol "([^"]+)"', blocks[p]) == ["control", "notify", "in", "out"]
+        assert "lv2:requiredFeature urid:map" in blocks[p]
     for p, n in want.items():
         idx = [int(i) for i in re.findall(r"lv2:index (\d+)", blocks[p])]
         assert idx == list(range(n)), p

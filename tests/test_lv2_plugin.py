@@ -8,7 +8,8 @@ import pytest
 import _signals as sig
 from _lv2host import MTR_URI, Host, Instance, arm_notify, forge_object, forge_sequence, notify_buffer, parse_sequence
 
-IN_SCOPE = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo"]
+IN_SCOPE = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
+            "SigDistHist", "bitmeter"]
 
 
 @pytest.fixture(scope="module")

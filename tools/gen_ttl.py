@@ -70,7 +70,8 @@ def spectr(stereo):
 
 def main(out):
     os.makedirs(out, exist_ok=True)
-    plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo"]
+    plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
+             "SigDistHist", "bitmeter"]
     man = PREFIX + "".join("mtr:%s\n\ta lv2:Plugin ;\n\tlv2:binary <meters_amd.so> ;\n\trdfs:seeAlso <meters_amd.ttl> .\n\n" % p
                            for p in plugs)
     open(os.path.join(out, "manifest.ttl"), "w").write(man)
@@ -103,6 +104,16 @@ def main(out):
                  ctl(6, "levelR", "Level R", "Output", 0.0, 1.0), ctl(7, "peakL", "Peak L", "Output", 0.0, 1.0),
                  ctl(8, "peakR", "Peak R", "Output", 0.0, 1.0)])
     t += plugin("spectr30stereo", "1/3 Octave Spectrum (Stereo, MI355X build)", "30-band 1/3-octave analyser; DSP on the GPU.", spectr(True))
+    # SigDistHist lv2ttl/meters.lv2.ttl.in:3255-3300, bitmeter :3376-3420: control / notify atom ports + one audio pair
+    for uri, name, comment in (("SigDistHist", "Signal Distribution Histogram (MI355X build)",
+                                "Histogram of sample values with mean / variance; counting on the GPU."),
+                               ("bitmeter", "Bitmeter (MI355X build)",
+                                "IEEE-754 bit-usage statistics of a float stream; counting on the GPU.")):
+        t += plugin(uri, name, comment,
+                    [atom_port(0, "control", "UI to plugin communication", "Input", "\t\tatom:supports time:Position ;\n"),
+                     atom_port(1, "notify", "plugin to UI communication", "Output", "\t\trsz:minimumSize 8192 ;\n"),
+                     audio(2, "in", "In", "Input"), audio(3, "out", "Out", "Output")],
+                    extra="\tlv2:requiredFeature urid:map ;\n")
     open(os.path.join(out, "meters_amd.ttl"), "w").write(t)
     print("wrote", out)
 
