@@ -326,7 +326,10 @@ int mtr_engine_intstat_reset (mtr_engine* e)
 	}
 	if (e->cfg.meters & MTR_METER_SIGDIST) {
 		if (e->sdh.reserve (S)) return fail (MTR_ERR_NOMEM, "hipMalloc sigdist state");
-		HIPCHK (hipMemset (e->sdh.p, 0, S * sizeof (mtr_sigdist_state)));
+		std::vector<mtr_sigdist_state> h (S);
+		memset (h.data (), 0, S * sizeof (mtr_sigdist_state));
+		for (auto& d : h) d.peak_bin = -1;                            // sdh_reset, src/sigdistlv2.c:54: no peak yet
+		HIPCHK (hipMemcpy (e->sdh.p, h.data (), S * sizeof (mtr_sigdist_state), hipMemcpyHostToDevice));
 	}
 	return MTR_OK;
 }

@@ -625,7 +625,8 @@ void mo_bitstats_run (mo_bitstats* b, const float* x, uint32_t n)
 	}
 }
 
-void mo_sigdist_reset (mo_sigdist* d) { memset (d, 0, sizeof (*d)); }
+/* sdh_reset  sigdistlv2.c:49-61 (hist_peakS = -1: no peak yet) */
+void mo_sigdist_reset (mo_sigdist* d) { memset (d, 0, sizeof (*d)); d->peak_bin = -1; }
 
 /* sigdistlv2.c:303-318 */
 void mo_sigdist_run (mo_sigdist* d, const float* x, uint32_t n)
