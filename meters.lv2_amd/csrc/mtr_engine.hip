@@ -538,6 +538,10 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ba.n_streams = S; ba.n_channels = e->cfg.n_channels; ba.omega = e->omega;
 		if (mtr_launch_bank (ba, st)) return fail (MTR_ERR_HIP, "k_bank launch");
 	}
+	// the integer tables are int32 (as the reference's, which stops counting at 2^31 - 1 samples); the
+	// kernels index a call's samples with 32 bits
+	if ((e->cfg.meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && n_frames >= 0x7fffffffull)
+		return fail (MTR_ERR_ARG, "BITSTATS / SIGDIST: n_frames per call must be < 2^31 - 1");
 	if (e->cfg.meters & MTR_METER_BITSTATS)
 		if (mtr_launch_bitstats (d_audio, stride, n_frames, e->bim.p, S, st)) return fail (MTR_ERR_HIP, "k_bitstats launch");
 	if (e->cfg.meters & MTR_METER_SIGDIST)

@@ -18,7 +18,7 @@ __global__ __launch_bounds__ (256) void k_sigdist (const float* audio, uint64_t 
 {
 #pragma clang fp contract(off)
 	__shared__ int32_t bins[MTR_DIST_BIN];
-	__shared__ unsigned long long last[MTR_DIST_BIN];   // index + 1 of the last sample that fell in the bin
+	__shared__ uint32_t last[MTR_DIST_BIN];              // in-call index + 1 of the last sample that fell in the bin
 	__shared__ double mom[256][3];                       // n, mean, M2 per lane, then combined
 	__shared__ double sums[256];
 	const int tid = threadIdx.x;
@@ -28,33 +28,45 @@ __global__ __launch_bounds__ (256) void k_sigdist (const float* audio, uint64_t 
 	for (int i = tid; i < MTR_DIST_BIN; i += 256) { bins[i] = 0; last[i] = 0; }
 	__syncthreads ();
 
-	// lane t takes samples t, t+256, ... (coalesced); its Welford state covers that subsequence and the
-	// 256 partial states are merged with Chan's pairwise formula (any partition gives the same moments)
-	double n = 0, mean = 0, m2 = 0, sum = 0;
+	// lane t takes samples t, t+256, ... (coalesced).  Its moments are kept as sums of d = v - K and d^2
+	// about a pivot K (the lane's first binned sample): as accurate as a Welford update — K lies inside
+	// the data — without its division per sample (~25 fp64 instructions); mean and M2 of the slice follow
+	// at the end and the 256 slices are merged with Chan's pairwise formula (any partition gives the same
+	// moments up to double rounding).
+	uint32_t cnt = 0;
+	double K = 0, s1 = 0, s2 = 0, sum = 0;
 	const uint64_t count0 = (uint64_t) o->count;
-	auto one = [&] (float val, uint64_t i) {
+	auto one = [&] (float val, uint32_t i) {
 		const float fb = rintf (180.f + val * 150.f);          // sigdistlv2.c:305
 		// `int bin = rintf (...)` then `if (bin < 0 || bin >= 361) continue`; NaN never passes
 		if (!(fb >= 0.f && fb < (float) MTR_DIST_BIN)) return;
 		const int bin = (int) fb;
 		atomicAdd (&bins[bin], 1);
-		atomicMax (&last[bin], (unsigned long long) (count0 + i + 1));
-		sum += val;
-		n += 1;
-		const double d = (double) val - mean;
-		mean += d / n;
-		m2 += ((double) val - mean) * d;
+		atomicMax (&last[bin], i + 1u);
+		const double v = (double) val;
+		if (cnt == 0) K = v;
+		const double d = v - K;
+		sum += v;
+		s1 += d;
+		s2 = fma (d, d, s2);
+		++cnt;
 	};
 	// 16-byte loads (4 samples per lane, 4 KiB per workgroup iteration) where the stream is aligned
 	const bool wide = ((((size_t) s * stride) & 3) == 0) && ((reinterpret_cast<size_t> (audio) & 15) == 0);
-	const uint64_t n4 = wide ? (n_frames / 4) : 0;
+	const uint32_t n4 = wide ? (uint32_t) (n_frames / 4) : 0;   // n_frames < 2^32 (checked by the engine)
 	const float4* src4 = reinterpret_cast<const float4*> (src);
-	for (uint64_t q = tid; q < n4; q += 256) {
+	for (uint32_t q = tid; q < n4; q += 256) {
 		const float4 v = src4[q];
 		one (v.x, 4 * q); one (v.y, 4 * q + 1); one (v.z, 4 * q + 2); one (v.w, 4 * q + 3);
 	}
-	for (uint64_t i = 4 * n4 + tid; i < n_frames; i += 256) one (src[i], i);
-	mom[tid][0] = n; mom[tid][1] = mean; mom[tid][2] = m2; sums[tid] = sum;
+	for (uint64_t i = (uint64_t) 4 * n4 + tid; i < n_frames; i += 256) one (src[i], (uint32_t) i);
+	{
+		const double nd = (double) cnt;
+		mom[tid][0] = nd;
+		mom[tid][1] = cnt ? K + s1 / nd : 0.0;
+		mom[tid][2] = cnt ? s2 - s1 * s1 / nd : 0.0;
+		sums[tid] = sum;
+	}
 	__syncthreads ();
 	if (tid == 0) {
 		// fold the carried moments and the 256 slices in stream order (Chan et al.)
@@ -72,7 +84,7 @@ __global__ __launch_bounds__ (256) void k_sigdist (const float* audio, uint64_t 
 	}
 	// histogram + peak: merge this call's bins into the persistent ones
 	for (int b = tid; b < MTR_DIST_BIN; b += 256) {
-		if (bins[b]) { o->bins[b] += bins[b]; o->last[b] = last[b]; }
+		if (bins[b]) { o->bins[b] += bins[b]; o->last[b] = count0 + last[b]; }
 	}
 	__syncthreads ();
 	__threadfence_block ();
