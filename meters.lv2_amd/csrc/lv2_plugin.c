@@ -13,6 +13,7 @@
  *   6      spectr30stereo
  *   7      SigDistHist     src/sigdistlv2.c (lv2_intstat.c) — signal-distribution histogram on the GPU, UI protocol + State
  *   8      bitmeter        src/bitmeter.c (lv2_intstat.c)   — IEEE-754 bit statistics on the GPU, UI protocol + State
+ *   9-24   BBC / EBU / DIN / NOR mono+stereo, COR, BBCM6, K12 / K14 / K20 mono+stereo (lv2_needle.c) — CPU plumbing
  *
  * The reference enumerates 38 plugins (src/meters.cc:745-792); LV2 hosts match by URI and stop at
  * the first NULL, so the in-scope subset is enumerated densely.
@@ -322,6 +323,13 @@ static const LV2_Descriptor descriptors[] = {
 	{ MTR_URI "spectr30stereo", spectrum_instantiate, spectrum_connect_port, NULL, spectrum_run, NULL, spectrum_cleanup, no_extension },
 	{ MTR_URI "SigDistHist",    sdh_instantiate,      intstat_connect_port,  NULL, sdh_run,      NULL, intstat_cleanup,  sdh_extension_data },
 	{ MTR_URI "bitmeter",       bim_instantiate,      intstat_connect_port,  NULL, bim_run,      NULL, intstat_cleanup,  bim_extension_data },
+#define NEEDLE(name, runfn) { MTR_URI name, needle_instantiate, needle_connect_port, NULL, runfn, NULL, needle_cleanup, no_extension }
+	NEEDLE ("BBCmono", needle_run), NEEDLE ("BBCstereo", needle_run), NEEDLE ("EBUmono", needle_run), NEEDLE ("EBUstereo", needle_run),
+	NEEDLE ("DINmono", needle_run), NEEDLE ("DINstereo", needle_run), NEEDLE ("NORmono", needle_run), NEEDLE ("NORstereo", needle_run),
+	NEEDLE ("COR", cor_run), NEEDLE ("BBCM6", bbcm_run),
+	NEEDLE ("K12mono", kmeter_run), NEEDLE ("K14mono", kmeter_run), NEEDLE ("K20mono", kmeter_run),
+	NEEDLE ("K12stereo", kmeter_run), NEEDLE ("K14stereo", kmeter_run), NEEDLE ("K20stereo", kmeter_run),
+#undef NEEDLE
 };
 
 LV2_SYMBOL_EXPORT const LV2_Descriptor* lv2_descriptor (uint32_t index)

@@ -22,4 +22,13 @@ const void* sdh_extension_data (const char* uri);
 void        intstat_connect_port (LV2_Handle h, uint32_t port, void* data);
 void        intstat_cleanup (LV2_Handle h);
 
+/* lv2_needle.c — the needle meters of src/meters.cc on jmeters/{iec1ppm,iec2ppm,msppm,stcorr,kmeter}dsp.cc (CPU) */
+LV2_Handle  needle_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features);
+void        needle_connect_port (LV2_Handle h, uint32_t port, void* data);
+void        needle_run (LV2_Handle h, uint32_t n_samples);
+void        cor_run (LV2_Handle h, uint32_t n_samples);
+void        bbcm_run (LV2_Handle h, uint32_t n_samples);
+void        kmeter_run (LV2_Handle h, uint32_t n_samples);
+void        needle_cleanup (LV2_Handle h);
+
 #endif

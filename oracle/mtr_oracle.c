@@ -573,6 +573,205 @@ void mo_vu_process (mo_vu* v, const float* p, int n)
 float mo_vu_read (mo_vu* v) { v->res = 1; return v->g * v->m; }
 
 /* ======================================================================
+ * PPM (IEC 268-10 type I: DIN / Nordic; type II: BBC / EBU), M/S PPM,
+ * stereo correlation, K-meter
+ * ====================================================================== */
+
+static void ppm_zero (mo_ppm* p) { p->z1 = p->z2 = p->m = 0; p->res = 1; }
+
+void mo_ppm_init_iec1 (mo_ppm* p, float fsamp)
+{
+	ppm_zero (p);
+	p->w1 = 450.0f / fsamp;
+	p->w2 = 1300.0f / fsamp;
+	p->w3 = 1.0f - 5.4f / fsamp;
+	p->g  = 0.5108f;
+}
+
+void mo_ppm_init_iec2 (mo_ppm* p, float fsamp)
+{
+	ppm_zero (p);
+	p->w1 = 200.0f / fsamp;
+	p->w2 = 860.0f / fsamp;
+	p->w3 = 1.0f - 4.0f / fsamp;
+	p->g  = 0.5141f;
+}
+
+/* one group of four rectified samples t[0..3] through the two attack filters; the decay is applied
+ * once per group (iec1ppmdsp.cc:58-74) */
+#define PPM_GROUP(T0, T1, T2, T3)                                  \
+	{                                                              \
+		float t;                                                   \
+		z1 *= w3; z2 *= w3;                                        \
+		t = (T0); if (t > z1) z1 += w1 * (t - z1); if (t > z2) z2 += w2 * (t - z2); \
+		t = (T1); if (t > z1) z1 += w1 * (t - z1); if (t > z2) z2 += w2 * (t - z2); \
+		t = (T2); if (t > z1) z1 += w1 * (t - z1); if (t > z2) z2 += w2 * (t - z2); \
+		t = (T3); if (t > z1) z1 += w1 * (t - z1); if (t > z2) z2 += w2 * (t - z2); \
+		t = z1 + z2;                                               \
+		if (t > m) m = t;                                          \
+	}
+
+void mo_ppm_process (mo_ppm* p, const float* in, int n)
+{
+	float z1 = p->z1 > 20 ? 20 : (p->z1 < 0 ? 0 : p->z1);
+	float z2 = p->z2 > 20 ? 20 : (p->z2 < 0 ? 0 : p->z2);
+	float m  = p->res ? 0 : p->m;
+	const float w1 = p->w1, w2 = p->w2, w3 = p->w3;
+	p->res = 0;
+	n /= 4;
+	while (n--) {
+		PPM_GROUP (fabsf (in[0]), fabsf (in[1]), fabsf (in[2]), fabsf (in[3]))
+		in += 4;
+	}
+	p->z1 = z1 + 1e-10f;
+	p->z2 = z2 + 1e-10f;
+	p->m = m;
+}
+
+float mo_ppm_read (mo_ppm* p) { p->res = 1; return p->g * p->m; }
+
+void mo_msppm_set_gain (mo_msppm* p, float db)
+{
+	if (p->db == db) return;
+	p->db = db;
+	p->mv = powf (10, .05 * db);
+}
+
+void mo_msppm_init (mo_msppm* p, float fsamp, float mdb)
+{
+	mo_ppm_init_iec2 (&p->p, fsamp);           /* the same constants, msppmdsp.cc:131-137 */
+	p->db = 0;
+	p->mv = 1.0f;
+	mo_msppm_set_gain (p, mdb);
+}
+
+void mo_msppm_process (mo_msppm* q, const float* l, const float* r, int n, int side)
+{
+	mo_ppm* p = &q->p;
+	float z1 = p->z1 > 20 ? 20 : (p->z1 < 0 ? 0 : p->z1);
+	float z2 = p->z2 > 20 ? 20 : (p->z2 < 0 ? 0 : p->z2);
+	float m  = p->res ? 0 : p->m;
+	const float w1 = p->w1, w2 = p->w2, w3 = p->w3, mv = q->mv;
+	p->res = 0;
+	n /= 4;
+	while (n--) {
+		if (side) {
+			PPM_GROUP (mv * fabsf (l[0] - r[0]), mv * fabsf (l[1] - r[1]), mv * fabsf (l[2] - r[2]), mv * fabsf (l[3] - r[3]))
+		} else {
+			PPM_GROUP (mv * fabsf (l[0] + r[0]), mv * fabsf (l[1] + r[1]), mv * fabsf (l[2] + r[2]), mv * fabsf (l[3] + r[3]))
+		}
+		l += 4; r += 4;
+	}
+	p->z1 = z1 + 1e-10f;
+	p->z2 = z2 + 1e-10f;
+	p->m = m;
+}
+
+float mo_msppm_read (mo_msppm* p) { return mo_ppm_read (&p->p); }
+
+void mo_stcorr_init (mo_stcorr* c, int fsamp, float flp, float tcf)
+{
+	c->zl = c->zr = c->zlr = c->zll = c->zrr = 0;
+	c->w1 = 6.28f * flp / fsamp;
+	c->w2 = 1 / (tcf * fsamp);
+}
+
+void mo_stcorr_process (mo_stcorr* c, const float* pl, const float* pr, int n)
+{
+	float zl = c->zl, zr = c->zr, zlr = c->zlr, zll = c->zll, zrr = c->zrr;
+	const float w1 = c->w1, w2 = c->w2;
+	while (n--) {
+		zl += w1 * (*pl++ - zl) + 1e-20f;
+		zr += w1 * (*pr++ - zr) + 1e-20f;
+		zlr += w2 * (zl * zr - zlr);
+		zll += w2 * (zl * zl - zll);
+		zrr += w2 * (zr * zr - zrr);
+	}
+	if (!isfinite (zl)) zl = 0;
+	if (!isfinite (zr)) zr = 0;
+	if (!isfinite (zlr)) zlr = 0;
+	if (!isfinite (zll)) zll = 0;
+	if (!isfinite (zrr)) zrr = 0;
+	c->zl = zl;
+	c->zr = zr;
+	c->zlr = zlr + 1e-10f;
+	c->zll = zll + 1e-10f;
+	c->zrr = zrr + 1e-10f;
+}
+
+float mo_stcorr_read (const mo_stcorr* c) { return c->zlr / sqrtf (c->zll * c->zrr + 1e-10f); }
+
+void mo_kmeter_reset (mo_kmeter* k)
+{
+	k->z1 = k->z2 = k->rms = k->peak = .0f;
+	k->cnt = 0;
+	k->flag = 0;
+}
+
+void mo_kmeter_init (mo_kmeter* k, float fsamp)
+{
+	mo_kmeter_reset (k);
+	k->fpp = 0;
+	k->fall = 0;
+	k->fsamp = fsamp;
+	k->hold = (int) (0.5f * fsamp + 0.5f);       /* samples to hold the peak */
+	k->omega = 9.72f / fsamp;                    /* ballistic filter coefficient */
+}
+
+void mo_kmeter_process (mo_kmeter* k, const float* p, int n)
+{
+	if (k->fpp != n) {
+		const float fall = 15.0f;
+		const float tme = (float) n / k->fsamp;  /* period time in seconds */
+		k->fall = powf (10.0f, -0.05f * fall * tme);
+		k->fpp = n;
+	}
+	float s, t = 0;
+	float z1 = k->z1 > 50 ? 50 : (k->z1 < 0 ? 0 : k->z1);
+	float z2 = k->z2 > 50 ? 50 : (k->z2 < 0 ? 0 : k->z2);
+	const float omega = k->omega;
+	n /= 4;
+	while (n--) {
+		for (int q = 0; q < 4; ++q) {
+			s = *p++;
+			s *= s;
+			if (t < s) t = s;                    /* digital peak */
+			z1 += omega * (s - z1);              /* first filter */
+		}
+		z2 += 4 * omega * (z1 - z2);             /* second filter, every 4th sample */
+	}
+	if (isnan (z1)) z1 = 0;
+	if (isnan (z2)) z2 = 0;
+	if (!isfinite (t)) t = 0;
+	k->z1 = z1 + 1e-20f;
+	k->z2 = z2 + 1e-20f;
+	s = sqrtf (2.0f * z2);
+	t = sqrtf (t);
+	if (k->flag) {                               /* the display has read the rms value */
+		k->rms = s;
+		k->flag = 0;
+	} else if (s > k->rms) {
+		k->rms = s;
+	}
+	if (t >= k->peak) {                          /* peak hold and fallback */
+		k->peak = t;
+		k->cnt = k->hold;
+	} else if (k->cnt > 0) {
+		k->cnt -= k->fpp;
+	} else {
+		k->peak *= k->fall;
+		k->peak += 1e-10f;
+	}
+}
+
+void mo_kmeter_read (mo_kmeter* k, float* rms, float* peak)
+{
+	*rms = k->rms;
+	*peak = k->peak;
+	k->flag = 1;
+}
+
+/* ======================================================================
  * Integer paths
  * ====================================================================== */
 

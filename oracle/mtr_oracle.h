@@ -146,6 +146,32 @@ void  mo_vu_init (mo_vu* v, float fsamp);                  /* vumeterdsp.cc:82-8
 void  mo_vu_process (mo_vu* v, const float* p, int n);     /* vumeterdsp.cc:45-73 */
 float mo_vu_read (mo_vu* v);                               /* vumeterdsp.cc:75-79 */
 
+/* ---- the other needle meters (CPU plumbing like VU) ---------------------- */
+
+/* Iec1ppmdsp (DIN / Nordic) and Iec2ppmdsp (BBC / EBU): the same loop, different constants */
+typedef struct { float z1, z2, m; int res; float w1, w2, w3, g; } mo_ppm;
+void  mo_ppm_init_iec1 (mo_ppm* p, float fsamp);           /* iec1ppmdsp.cc:89-95 */
+void  mo_ppm_init_iec2 (mo_ppm* p, float fsamp);           /* iec2ppmdsp.cc:89-95 */
+void  mo_ppm_process (mo_ppm* p, const float* in, int n);  /* iec1ppmdsp.cc:47-79 = iec2ppmdsp.cc:45-79 */
+float mo_ppm_read (mo_ppm* p);                             /* iec1ppmdsp.cc:82-86 */
+/* Msppmdsp: the IEC2 loop on L+R (M) or L-R (S), scaled by 10^(dB/20) */
+typedef struct { mo_ppm p; float db, mv; } mo_msppm;
+void  mo_msppm_init (mo_msppm* p, float fsamp, float mdb); /* msppmdsp.cc:34-43, 131-137 */
+void  mo_msppm_set_gain (mo_msppm* p, float db);           /* msppmdsp.cc:140-148 */
+void  mo_msppm_process (mo_msppm* p, const float* l, const float* r, int n, int side);   /* :50-81 (M), :83-114 (S) */
+float mo_msppm_read (mo_msppm* p);                         /* msppmdsp.cc:117-121 */
+/* Stcorrdsp: stereo phase correlation */
+typedef struct { float zl, zr, zlr, zll, zrr, w1, w2; } mo_stcorr;
+void  mo_stcorr_init (mo_stcorr* c, int fsamp, float flp, float tcf);   /* stcorrdsp.cc:84-93 */
+void  mo_stcorr_process (mo_stcorr* c, const float* l, const float* r, int n);   /* stcorrdsp.cc:47-76 */
+float mo_stcorr_read (const mo_stcorr* c);                 /* stcorrdsp.cc:79-82 */
+/* Kmeterdsp: RMS with ballistics + digital peak with hold and fallback */
+typedef struct { float z1, z2, rms, peak; int cnt, fpp; float fall; int flag; int hold; float fsamp, omega; } mo_kmeter;
+void  mo_kmeter_init (mo_kmeter* k, float fsamp);          /* kmeterdsp.cc:47-54 */
+void  mo_kmeter_process (mo_kmeter* k, const float* p, int n);   /* kmeterdsp.cc:56-138 */
+void  mo_kmeter_read (mo_kmeter* k, float* rms, float* peak);    /* kmeterdsp.cc:148-153 */
+void  mo_kmeter_reset (mo_kmeter* k);                      /* kmeterdsp.cc:155-160 */
+
 /* ---- integer paths ---------------------------------------------------- */
 
 typedef struct {

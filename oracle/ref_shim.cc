@@ -31,6 +31,11 @@
 #include "ebumeter/ebu_r128_proc.h"
 #include "jmeters/truepeakdsp.h"
 #include "jmeters/vumeterdsp.h"
+#include "jmeters/iec1ppmdsp.h"
+#include "jmeters/iec2ppmdsp.h"
+#include "jmeters/msppmdsp.h"
+#include "jmeters/stcorrdsp.h"
+#include "jmeters/kmeterdsp.h"
 
 namespace refspectr {
 #include "src/spectr.c"
@@ -259,5 +264,36 @@ void* ref_vu_new (float fsamp)
 void  ref_vu_free (void* h) { delete (Vumeterdsp*) h; }
 void  ref_vu_process (void* h, float* p, int n) { ((Vumeterdsp*) h)->process (p, n); }
 float ref_vu_read (void* h) { return ((Vumeterdsp*) h)->read (); }
+
+/* ---- the other needle meters: kind 1 = Iec1ppmdsp, 2 = Iec2ppmdsp ----------------------------- */
+
+void* ref_ppm_new (int kind, float fsamp)
+{
+	if (kind == 1) { Iec1ppmdsp* p = new Iec1ppmdsp (); Iec1ppmdsp::init (fsamp); return p; }
+	Iec2ppmdsp* p = new Iec2ppmdsp (); Iec2ppmdsp::init (fsamp); return p;
+}
+void  ref_ppm_free (void* h) { delete (JmeterDSP*) h; }
+void  ref_ppm_process (void* h, float* p, int n) { ((JmeterDSP*) h)->process (p, n); }
+float ref_ppm_read (void* h) { return ((JmeterDSP*) h)->read (); }
+
+void* ref_msppm_new (float fsamp, float mdb) { Msppmdsp* p = new Msppmdsp (mdb); Msppmdsp::init (fsamp); return p; }
+void  ref_msppm_free (void* h) { delete (Msppmdsp*) h; }
+void  ref_msppm_set_gain (void* h, float db) { ((Msppmdsp*) h)->set_gain (db); }
+void  ref_msppm_process (void* h, float* l, float* r, int n, int side)
+{
+	if (side) ((Msppmdsp*) h)->processS (l, r, n); else ((Msppmdsp*) h)->processM (l, r, n);
+}
+float ref_msppm_read (void* h) { return ((Msppmdsp*) h)->read (); }
+
+void* ref_stcorr_new (int fsamp, float flp, float tcf) { Stcorrdsp* c = new Stcorrdsp (); c->init (fsamp, flp, tcf); return c; }
+void  ref_stcorr_free (void* h) { delete (Stcorrdsp*) h; }
+void  ref_stcorr_process (void* h, float* l, float* r, int n) { ((Stcorrdsp*) h)->process (l, r, n); }
+float ref_stcorr_read (void* h) { return ((Stcorrdsp*) h)->read (); }
+
+void* ref_kmeter_new (float fsamp) { Kmeterdsp* k = new Kmeterdsp (); k->init (fsamp); return k; }
+void  ref_kmeter_free (void* h) { delete (Kmeterdsp*) h; }
+void  ref_kmeter_process (void* h, float* p, int n) { ((Kmeterdsp*) h)->process (p, n); }
+void  ref_kmeter_read (void* h, float* rms, float* peak) { ((Kmeterdsp*) h)->read (*rms, *peak); }
+void  ref_kmeter_reset (void* h) { ((Kmeterdsp*) h)->reset (); }
 
 } /* extern "C" */

@@ -19,6 +19,11 @@ def test_ttl_matches_the_plugin_port_maps(tmp_path):
     blocks = {p: ttl.split(f"mtr:{p}\n")[1].split("\n\t.\n")[0] for p in plugs}
     want = {"VUmono": 4, "VUstereo": 7, "EBUr128": 6, "spectr30mono": 66, "dBTPmono": 5, "dBTPstereo": 9,
             "spectr30stereo": 68, "SigDistHist": 4, "bitmeter": 4}
+    needles = {"BBCmono": 4, "EBUstereo": 7, "DINmono": 4, "NORstereo": 7, "COR": 6, "BBCM6": 8, "K14mono": 6, "K20stereo": 10}
+    for p, n in needles.items():
+        assert f"mtr:{p}\n" in man
+        blk = ttl.split(f"mtr:{p}\n")[1].split("\n\t.\n")[0]
+        assert [int(i) for i in re.findall(r"lv2:index (\d+)", blk)] == list(range(n)), p
     for p in ("SigDistHist", "bitmeter"):
         assert re.findall(r'lv2:symbol "([^"]+)"', blocks[p]) == ["control", "notify", "in", "out"]
         assert "lv2:requiredFeature urid:map" in blocks[p]

@@ -9,7 +9,9 @@ import _signals as sig
 from _lv2host import MTR_URI, Host, Instance, arm_notify, forge_object, forge_sequence, notify_buffer, parse_sequence
 
 IN_SCOPE = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
-            "SigDistHist", "bitmeter"]
+            "SigDistHist", "bitmeter",
+            "BBCmono", "BBCstereo", "EBUmono", "EBUstereo", "DINmono", "DINstereo", "NORmono", "NORstereo", "COR", "BBCM6",
+            "K12mono", "K14mono", "K20mono", "K12stereo", "K14stereo", "K20stereo"]
 
 
 @pytest.fixture(scope="module")

@@ -68,10 +68,51 @@ def spectr(stereo):
     return p
 
 
+NEEDLES = ["BBCmono", "BBCstereo", "EBUmono", "EBUstereo", "DINmono", "DINstereo", "NORmono", "NORstereo", "COR", "BBCM6",
+           "K12mono", "K14mono", "K20mono", "K12stereo", "K14stereo", "K20stereo"]
+NEEDLE_NAMES = {"BBC": "BBC PPM", "EBU": "EBU PPM", "DIN": "DIN PPM", "NOR": "Nordic PPM",
+                "K12": "K12/RMS Meter", "K14": "K14/RMS Meter", "K20": "K20/RMS Meter"}
+
+
+def needles():
+    """The needle meters share VU's port map (lv2ttl/meters.lv2.ttl.in: port indices of src/meters.cc:59-70);
+    the K-meters add peak and hold outputs (mono: on the otherwise unused indices 4 and 5)."""
+    t = ""
+    for n in NEEDLES:
+        if n == "COR":
+            ports = [ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, -18.0), audio(1, "inL", "InL", "Input"),
+                     audio(2, "outL", "OutL", "Output"), ctl(3, "level", "Correlation", "Output", -1.0, 1.0),
+                     audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output")]
+            t += plugin(n, "Stereo Phase-Correlation Meter (MI355X build)", "Stereo phase correlation; host CPU.", ports)
+            continue
+        if n == "BBCM6":
+            ports = [ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, -18.0), audio(1, "inL", "InL", "Input"),
+                     audio(2, "outL", "OutL", "Output"), ctl(3, "levelM", "Level M", "Output", 0.0, 1.0),
+                     audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output"),
+                     ctl(6, "levelS", "Level S", "Output", 0.0, 1.0), ctl(7, "gainS", "S +20 dB", "Input", 0, 1, 0)]
+            t += plugin(n, "BBC M-6 PPM (MI355X build)", "Mid / side peak programme meter; host CPU.", ports)
+            continue
+        kind, stereo = n[:3], n.endswith("stereo")
+        label = "%s (%s, MI355X build)" % (NEEDLE_NAMES[kind], "Stereo" if stereo else "Mono")
+        ports = [ctl(0, "ref", "Reference level", "Input", -30.0, 3.0, -18.0)]
+        if not stereo:
+            ports += [audio(1, "in", "In", "Input"), audio(2, "out", "Out", "Output"), ctl(3, "level", "Level", "Output", 0.0, 2.0)]
+            if kind[0] == "K":
+                ports += [ctl(4, "peak", "Peak", "Output", 0.0, 2.0), ctl(5, "hold", "Peak hold", "Output", -70000.0, 2.0)]
+        else:
+            ports += [audio(1, "inL", "InL", "Input"), audio(2, "outL", "OutL", "Output"), ctl(3, "levelL", "Level L", "Output", 0.0, 2.0),
+                      audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output"), ctl(6, "levelR", "Level R", "Output", 0.0, 2.0)]
+            if kind[0] == "K":
+                ports += [ctl(7, "peakL", "Peak L", "Output", 0.0, 2.0), ctl(8, "peakR", "Peak R", "Output", 0.0, 2.0),
+                          ctl(9, "hold", "Peak hold", "Output", -70000.0, 2.0)]
+        t += plugin(n, label, "Needle meter ballistics on the host CPU.", ports)
+    return t
+
+
 def main(out):
     os.makedirs(out, exist_ok=True)
     plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
-             "SigDistHist", "bitmeter"]
+             "SigDistHist", "bitmeter"] + NEEDLES
     man = PREFIX + "".join("mtr:%s\n\ta lv2:Plugin ;\n\tlv2:binary <meters_amd.so> ;\n\trdfs:seeAlso <meters_amd.ttl> .\n\n" % p
                            for p in plugs)
     open(os.path.join(out, "manifest.ttl"), "w").write(man)
@@ -114,6 +155,7 @@ def main(out):
                      atom_port(1, "notify", "plugin to UI communication", "Output", "\t\trsz:minimumSize 8192 ;\n"),
                      audio(2, "in", "In", "Input"), audio(3, "out", "Out", "Output")],
                     extra="\tlv2:requiredFeature urid:map ;\n")
+    t += needles()
     open(os.path.join(out, "meters_amd.ttl"), "w").write(t)
     print("wrote", out)
 
