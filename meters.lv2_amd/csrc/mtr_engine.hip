@@ -75,7 +75,8 @@ struct mtr_engine {
 	DevBuf<float>    agg_max;
 	DevBuf<mtr_bitstats_state> bim;
 	DevBuf<mtr_sigdist_state>  sdh;
-	DevBuf<float>    fir_g;         // [3][48] taps in device memory (ballistics kernel)
+	DevBuf<float>    fir_g;         // [3][48] taps in device memory
+	DevBuf<float>    fir_pmq;       // [3][24] the same in mirror-symmetric form (ballistics kernel)
 	DevBuf<uint32_t> prune_cnt;     // [2] interpolator tile passes considered / skipped
 	uint64_t         prune_tot[2] = { 0, 0 };
 	float            tpb_w[4];      // w1 w2 w3 g of TruePeakdsp::init
@@ -151,6 +152,17 @@ static int upload_consts (mtr_engine* e)
 	if (e->fir_g.reserve (144) || e->prune_cnt.reserve (2)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_g");
 	HIPCHK (hipMemset (e->prune_cnt.p, 0, 8));
 	HIPCHK (hipMemcpy (e->fir_g.p, g, sizeof (g), hipMemcpyHostToDevice));
+	{
+		// the same taps in the mirror-symmetric form (P, M, Q of mtr_fused2.hip) for the ballistics kernel
+		float pmq[3][24];
+		for (int i = 0; i < 24; ++i) {
+			pmq[0][i] = (float) (((double) g[0][i] + (double) g[0][47 - i]) * 0.5);
+			pmq[1][i] = (float) (((double) g[0][i] - (double) g[0][47 - i]) * 0.5);
+			pmq[2][i] = g[1][i];
+		}
+		if (e->fir_pmq.reserve (72)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_pmq");
+		HIPCHK (hipMemcpy (e->fir_pmq.p, pmq, sizeof (pmq), hipMemcpyHostToDevice));
+	}
 	// TruePeakdsp::init, jmeters/truepeakdsp.cc:154-157 — float / float / double, stored as float
 	const float fs = e->cfg.sample_rate;
 	e->tpb_w[0] = 4000.0f / fs / 4.0;
@@ -550,7 +562,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (tpb) {
 		mtr_tpb_args ta;
 		ta.audio = d_audio; ta.stride = stride; ta.n_frames = n_frames;
-		ta.hist = e->fir_hist[e->hist_cur].p; ta.fir_g = e->fir_g.p; ta.state = e->state.p;
+		ta.hist = e->fir_hist[e->hist_cur].p; ta.fir_g = e->fir_g.p; ta.fir_pmq = e->fir_pmq.p; ta.state = e->state.p;
 		ta.n_streams = S; ta.n_channels = e->cfg.n_channels;
 		ta.w1 = e->tpb_w[0]; ta.w2 = e->tpb_w[1]; ta.w3 = e->tpb_w[2]; ta.g = e->tpb_w[3];
 		if (mtr_launch_tpb (ta, st)) return fail (MTR_ERR_HIP, "k_tpb launch");

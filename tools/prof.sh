@@ -28,6 +28,6 @@ for p in ("pmc1","pmc2","pmc3","pmc4"):
             acc[k][0] += float(row.get("Counter_Value", 0)); acc[k][1] += 1
         print("==", p)
         for k, (v, n) in sorted(acc.items()):
-            if any(t in k[0] for t in ("fused", "bank", "gate", "k_kw", "bitstats", "sigdist")):
+            if any(t in k[0] for t in ("fused", "bank", "gate", "k_kw", "bitstats", "sigdist", "k_tpb")):
                 print(k, "avg/dispatch = %.4g" % (v / n), "n =", n)
 PY
