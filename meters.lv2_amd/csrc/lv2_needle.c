@@ -17,6 +17,7 @@
 
 #include "lv2_min.h"
 #include "lv2_plugins.h"
+#include "lv2_dsp.h"
 
 #define MTR_URI "http://gareus.org/oss/lv2/meters#"
 
@@ -80,40 +81,7 @@ static void cor_process (Cor* c, const float* pl, const float* pr, int n)
 	c->zrr = (isfinite (zrr) ? zrr : 0) + 1e-10f;
 }
 
-/* ---- K-meter, kmeterdsp.cc:47-160 ---- */
-typedef struct { float z1, z2, rms, peak, fall, fsamp, omega; int cnt, fpp, hold, flag; } Kmeter;
-static void km_reset (Kmeter* k) { k->z1 = k->z2 = k->rms = k->peak = 0; k->cnt = 0; k->flag = 0; }
-static void km_process (Kmeter* k, const float* p, int n)
-{
-	if (k->fpp != n) {                           /* per-period fallback multiplier: 15 dB/s */
-		k->fall = powf (10.0f, -0.05f * 15.0f * ((float) n / k->fsamp));
-		k->fpp = n;
-	}
-	float t = 0;
-	float z1 = k->z1 > 50 ? 50 : (k->z1 < 0 ? 0 : k->z1);
-	float z2 = k->z2 > 50 ? 50 : (k->z2 < 0 ? 0 : k->z2);
-	for (n /= 4; n > 0; --n) {
-		for (int q = 0; q < 4; ++q) {
-			float s = *p++;
-			s *= s;
-			if (t < s) t = s;
-			z1 += k->omega * (s - z1);
-		}
-		z2 += 4 * k->omega * (z1 - z2);
-	}
-	if (isnan (z1)) z1 = 0;
-	if (isnan (z2)) z2 = 0;
-	if (!isfinite (t)) t = 0;
-	k->z1 = z1 + 1e-20f;
-	k->z2 = z2 + 1e-20f;
-	const float s = sqrtf (2.0f * z2);
-	t = sqrtf (t);
-	if (k->flag) { k->rms = s; k->flag = 0; }
-	else if (s > k->rms) k->rms = s;
-	if (t >= k->peak) { k->peak = t; k->cnt = k->hold; }
-	else if (k->cnt > 0) k->cnt -= k->fpp;
-	else { k->peak *= k->fall; k->peak += 1e-10f; }
-}
+/* ---- K-meter: lv2_dsp.h (shared with the DR14 / TP+RMS plugins) ---- */
 
 /* ---- the instance, LV2meter of src/meters.cc:91-148 reduced to what these plugins use ---- */
 enum { P_REFLEVEL = 0, P_INPUT0, P_OUTPUT0, P_LEVEL0, P_INPUT1, P_OUTPUT1, P_LEVEL1, P_PEAK0, P_PEAK1, P_HOLD };   /* :59-70 */
@@ -171,12 +139,7 @@ LV2_Handle needle_instantiate (const LV2_Descriptor* d, double rate, const char*
 		self->type = kinds[i].type;
 		for (uint32_t c = 0; c < self->chn; ++c) {
 			if (self->type == T_PPM) ppm_init (&self->ppm[c], kinds[i].ppm, (float) rate);
-			else {                               /* Kmeterdsp::init, kmeterdsp.cc:47-54 */
-				memset (&self->km[c], 0, sizeof (Kmeter));
-				self->km[c].fsamp = (float) rate;
-				self->km[c].hold = (int) (0.5f * (float) rate + 0.5f);
-				self->km[c].omega = 9.72f / (float) rate;
-			}
+			else km_init (&self->km[c], (float) rate);
 		}
 		return self;
 	}

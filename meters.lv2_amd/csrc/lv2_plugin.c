@@ -14,6 +14,7 @@
  *   7      SigDistHist     src/sigdistlv2.c (lv2_intstat.c) — signal-distribution histogram on the GPU, UI protocol + State
  *   8      bitmeter        src/bitmeter.c (lv2_intstat.c)   — IEEE-754 bit statistics on the GPU, UI protocol + State
  *   9-24   BBC / EBU / DIN / NOR mono+stereo, COR, BBCM6, K12 / K14 / K20 mono+stereo (lv2_needle.c) — CPU plumbing
+ *   25-28  dr14mono/stereo, TPnRMSmono/stereo   src/dr14.c (lv2_dr14.c) — true-peak ballistics on the GPU
  *
  * The reference enumerates 38 plugins (src/meters.cc:745-792); LV2 hosts match by URI and stop at
  * the first NULL, so the in-scope subset is enumerated densely.
@@ -330,6 +331,9 @@ static const LV2_Descriptor descriptors[] = {
 	NEEDLE ("K12mono", kmeter_run), NEEDLE ("K14mono", kmeter_run), NEEDLE ("K20mono", kmeter_run),
 	NEEDLE ("K12stereo", kmeter_run), NEEDLE ("K14stereo", kmeter_run), NEEDLE ("K20stereo", kmeter_run),
 #undef NEEDLE
+#define DR14(name) { MTR_URI name, dr14_instantiate, dr14_connect_port, NULL, dr14_run, NULL, dr14_cleanup, no_extension }
+	DR14 ("dr14mono"), DR14 ("dr14stereo"), DR14 ("TPnRMSmono"), DR14 ("TPnRMSstereo"),
+#undef DR14
 };
 
 LV2_SYMBOL_EXPORT const LV2_Descriptor* lv2_descriptor (uint32_t index)

@@ -31,4 +31,10 @@ void        bbcm_run (LV2_Handle h, uint32_t n_samples);
 void        kmeter_run (LV2_Handle h, uint32_t n_samples);
 void        needle_cleanup (LV2_Handle h);
 
+/* lv2_dr14.c — src/dr14.c: DR-14 and true-peak + RMS */
+LV2_Handle  dr14_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features);
+void        dr14_connect_port (LV2_Handle h, uint32_t port, void* data);
+void        dr14_run (LV2_Handle h, uint32_t n_samples);
+void        dr14_cleanup (LV2_Handle h);
+
 #endif

@@ -772,6 +772,152 @@ void mo_kmeter_read (mo_kmeter* k, float* rms, float* peak)
 }
 
 /* ======================================================================
+ * DR-14 / TP+RMS (src/dr14.c)
+ * ====================================================================== */
+
+static float dr_coeff_to_db (const float coeff)              /* dr14.c:235-238 */
+{
+	if (coeff < .0001) return -80;
+	return 20 * log10f (coeff);
+}
+
+static float dr_db_to_coeff (const float db)                 /* dr14.c:240-243 */
+{
+	if (db <= -80) return 0;
+	return powf (10, 0.05 * db);
+}
+
+void mo_dr14_reset (mo_dr14* d)
+{
+	for (int c = 0; c < d->n_channels; ++c) {
+		d->m_peak[c] = -81;
+		d->m_rms[c] = -81;
+		d->m_dbtp[c] = 0;
+		d->rms_sum[c] = 0;
+		d->peak_cur[c] = 0;
+		d->peak_hist[c][0] = d->peak_hist[c][1] = 0;
+		mo_kmeter_reset (&d->km[c]);
+		if (d->dr_mode) memset (d->hist[c], 0, sizeof (d->hist[c]));
+	}
+	d->sample_count = 0;
+	d->num_fragments = 0;
+}
+
+void mo_dr14_init (mo_dr14* d, int n_channels, int dr_mode, double rate)
+{
+	memset (d, 0, sizeof (*d));
+	d->n_channels = n_channels;
+	d->dr_mode = dr_mode;
+	d->rate = rate;
+	d->n_sample_cnt = rintf (rate * 3.0);
+	for (int c = 0; c < n_channels; ++c) {
+		mo_kmeter_init (&d->km[c], rate);
+		mo_tp_init (&d->tp[c], rate);
+		d->m_rms[c] = -81;
+		d->m_peak[c] = -81;
+	}
+}
+
+/* dr14_calc_rms_score  dr14.c:283-352 */
+static void dr14_window (mo_dr14* d)
+{
+	int silent = 1;
+	for (int c = 0; c < d->n_channels; ++c)
+		if (d->rms_sum[c] > 1e-9 * (float) d->n_sample_cnt) silent = 0;
+	if (silent) {
+		for (int c = 0; c < d->n_channels; ++c) d->rms_sum[c] = 0;
+		return;
+	}
+	d->num_fragments++;
+	float cutf = floorf (d->num_fragments / 5.0);
+	const uint32_t m_cut = cutf > 1 ? cutf : 1;
+	for (int c = 0; c < d->n_channels; ++c) {
+		float rms = sqrt (2.f * d->rms_sum[c] / (float) d->n_sample_cnt);
+		d->rms_sum[c] = 0;
+		int bin = rintf (100.f * (80.f + dr_coeff_to_db (rms))) - 1;
+		if (bin >= MO_DR_HISTBINS) bin = MO_DR_HISTBINS - 1;
+		if (bin > 0) d->hist[c][bin]++;
+		uint32_t n_cut = 0;
+		float rms_score = 0;
+		if (d->num_fragments > 2) {
+			for (int32_t b = MO_DR_HISTBINS - 1; b > 0 && n_cut < m_cut; --b) {
+				const uint32_t bc = d->hist[c][b];
+				if (bc == 0) continue;
+				const float cd = dr_db_to_coeff ((b - MO_DR_HISTBINS + 1) / 100.0);
+				rms_score += cd * cd * (float) bc;
+				n_cut += bc;
+			}
+		}
+		if (n_cut > 0) rms_score = dr_coeff_to_db (sqrtf (rms_score / n_cut));
+		else rms_score = -81;
+		d->m_rms[c] = rms_score;
+		if (d->peak_cur[c] >= d->peak_hist[c][0]) {
+			d->peak_hist[c][1] = d->peak_hist[c][0];
+			d->peak_hist[c][0] = d->peak_cur[c];
+		} else if (d->peak_cur[c] > d->peak_hist[c][1]) {
+			d->peak_hist[c][1] = d->peak_cur[c];
+		}
+		d->peak_cur[c] = 0;
+		d->m_peak[c] = d->num_fragments > 2 ? dr_coeff_to_db (d->peak_hist[c][1]) : -81;
+	}
+}
+
+void mo_dr14_run (mo_dr14* d, const float* const* in, uint32_t n, mo_dr14_ports* out)
+{
+	for (int c = 0; c < d->n_channels; ++c) {
+		mo_kmeter_process (&d->km[c], in[c], n);
+		mo_tp_process (&d->tp[c], in[c], n);
+	}
+	if (d->dr_mode) {
+		uint64_t scnt = d->sample_count;
+		for (uint32_t s = 0; s < n; ++s) {
+			for (int c = 0; c < d->n_channels; ++c) {
+				const float v = in[c][s];
+				d->rms_sum[c] += v * v;
+				d->peak_cur[c] = d->peak_cur[c] > v ? d->peak_cur[c] : v;
+			}
+			if (++scnt > d->n_sample_cnt) {
+				dr14_window (d);
+				scnt = 0;
+			}
+		}
+		d->sample_count = scnt;
+	}
+	float dr_total = 0;
+	int dr_valid = 0;
+	memset (out, 0, sizeof (*out));
+	for (int c = 0; c < d->n_channels; ++c) {
+		float rv, rp, pv, pp;
+		mo_tp_read2 (&d->tp[c], &pv, &pp);
+		mo_kmeter_read (&d->km[c], &rv, &rp);
+		if (pp > d->m_dbtp[c]) d->m_dbtp[c] = pp;
+		out->v_rms[c] = dr_coeff_to_db (rv);
+		out->v_peak[c] = dr_coeff_to_db (pv);
+		out->m_peak[c] = dr_coeff_to_db (d->m_dbtp[c]);
+		if (d->dr_mode) {
+			const float rdb = d->m_rms[c], pdb = d->m_peak[c];
+			const float dr = (0 < pdb ? 0 : pdb) - rdb;
+			if (rdb > -80 && pdb > -80) { dr_total += dr; dr_valid++; }
+			const float cl = 20 < dr ? 20 : dr;
+			out->dr[c] = (rdb > -80 && pdb > -80) ? (1 > cl ? 1 : cl) : 21;
+			out->m_rms[c] = rdb;
+		} else {
+			out->m_rms[c] = dr_coeff_to_db (rp);
+		}
+	}
+	if (d->n_channels > 1 && d->dr_mode) {
+		if (dr_valid > 0) {
+			const float a = dr_total / (float) dr_valid;
+			const float cl = 20 < a ? 20 : a;
+			out->dr_total = 1 > cl ? 1 : cl;
+		} else {
+			out->dr_total = 21;
+		}
+	}
+	out->block_count = 3.0 * d->num_fragments;
+}
+
+/* ======================================================================
  * Integer paths
  * ====================================================================== */
 

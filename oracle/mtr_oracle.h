@@ -172,6 +172,25 @@ void  mo_kmeter_process (mo_kmeter* k, const float* p, int n);   /* kmeterdsp.cc
 void  mo_kmeter_read (mo_kmeter* k, float* rms, float* peak);    /* kmeterdsp.cc:148-153 */
 void  mo_kmeter_reset (mo_kmeter* k);                      /* kmeterdsp.cc:155-160 */
 
+/* ---- DR-14 / TP+RMS (src/dr14.c; needs the LV2 headers, so this part is parity-unpinned by the
+ *      reference build: restated from the source, the DSP objects underneath are pinned) -------- */
+#define MO_DR_HISTBINS 8000
+typedef struct {
+	int      n_channels, dr_mode;
+	double   rate;
+	uint64_t n_sample_cnt, sample_count, num_fragments;
+	float    m_dbtp[2], m_peak[2], m_rms[2];
+	float    rms_sum[2], peak_cur[2], peak_hist[2][2];
+	mo_kmeter km[2];
+	mo_tp     tp[2];
+	uint32_t  hist[2][MO_DR_HISTBINS];
+} mo_dr14;
+/* the port values dr14_run leaves behind (src/dr14.c:413-451) */
+typedef struct { float v_rms[2], v_peak[2], m_rms[2], m_peak[2], dr[2], dr_total, block_count; } mo_dr14_ports;
+void  mo_dr14_init (mo_dr14* d, int n_channels, int dr_mode, double rate);   /* dr14.c:108-166 */
+void  mo_dr14_reset (mo_dr14* d);                                            /* reset_peaks :245-260 */
+void  mo_dr14_run (mo_dr14* d, const float* const* in, uint32_t n, mo_dr14_ports* out);   /* :354-453 */
+
 /* ---- integer paths ---------------------------------------------------- */
 
 typedef struct {

@@ -11,7 +11,8 @@ from _lv2host import MTR_URI, Host, Instance, arm_notify, forge_object, forge_se
 IN_SCOPE = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
             "SigDistHist", "bitmeter",
             "BBCmono", "BBCstereo", "EBUmono", "EBUstereo", "DINmono", "DINstereo", "NORmono", "NORstereo", "COR", "BBCM6",
-            "K12mono", "K14mono", "K20mono", "K12stereo", "K14stereo", "K20stereo"]
+            "K12mono", "K14mono", "K20mono", "K12stereo", "K14stereo", "K20stereo",
+            "dr14mono", "dr14stereo", "TPnRMSmono", "TPnRMSstereo"]
 
 
 @pytest.fixture(scope="module")

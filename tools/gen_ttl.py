@@ -109,10 +109,40 @@ def needles():
     return t
 
 
+DR14S = ["dr14mono", "dr14stereo", "TPnRMSmono", "TPnRMSstereo"]
+
+
+def dr14s():
+    """src/dr14.c:27-43: control atom port, three control ports, then per channel audio in / out and five bar values;
+    stereo adds the averaged DR value."""
+    t = ""
+    for n in DR14S:
+        stereo = n.endswith("stereo")
+        ports = [atom_port(0, "control", "UI to plugin communication", "Input", "\t\tatom:supports time:Position ;\n"),
+                 ctl(1, "follow_transport", "Reset when the transport starts", "Input", 0, 1, 1),
+                 ctl(2, "reset", "Reset", "Input", 0, 1, 0),
+                 ctl(3, "blkcnt", "Integration time [s]", "Output", -70000.0, 360000.0)]
+        for c, suf in enumerate(("L", "R") if stereo else ("",)):
+            b = 4 + 7 * c
+            ports += [audio(b, "in" + suf, "In" + suf, "Input"), audio(b + 1, "out" + suf, "Out" + suf, "Output"),
+                      ctl(b + 2, "peak" + suf, "True peak " + suf, "Output", -80.0, 6.0),
+                      ctl(b + 3, "peak_max" + suf, "True peak max " + suf, "Output", -100.0, 6.0),
+                      ctl(b + 4, "rms" + suf, "RMS " + suf, "Output", -80.0, 6.0),
+                      ctl(b + 5, "rms_max" + suf, "RMS max " + suf, "Output", -100.0, 6.0),
+                      ctl(b + 6, "dr" + suf, "DR " + suf, "Output", 1.0, 21.0)]
+        if stereo:
+            ports.append(ctl(18, "dr_total", "DR", "Output", 1.0, 21.0))
+        label = ("DR-14 Crest-Factor Meter" if n.startswith("dr14") else "True-Peak and RMS Meter") + \
+            (" (Stereo, MI355X build)" if stereo else " (Mono, MI355X build)")
+        t += plugin(n, label, "True-peak ballistics on the GPU; RMS and 3 s window statistics on the host.", ports,
+                    extra="\tlv2:requiredFeature urid:map ;\n")
+    return t
+
+
 def main(out):
     os.makedirs(out, exist_ok=True)
     plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
-             "SigDistHist", "bitmeter"] + NEEDLES
+             "SigDistHist", "bitmeter"] + NEEDLES + DR14S
     man = PREFIX + "".join("mtr:%s\n\ta lv2:Plugin ;\n\tlv2:binary <meters_amd.so> ;\n\trdfs:seeAlso <meters_amd.ttl> .\n\n" % p
                            for p in plugs)
     open(os.path.join(out, "manifest.ttl"), "w").write(man)
@@ -156,6 +186,7 @@ def main(out):
                      audio(2, "in", "In", "Input"), audio(3, "out", "Out", "Output")],
                     extra="\tlv2:requiredFeature urid:map ;\n")
     t += needles()
+    t += dr14s()
     open(os.path.join(out, "meters_amd.ttl"), "w").write(t)
     print("wrote", out)
 
