@@ -168,7 +168,7 @@ def test_time_segments_and_tile_shapes(M, oracle, run, segs):
         assert np.allclose(r["tp"][s], oracle.tp(x[s], 48000.0, 8192), rtol=2e-6)
 
 
-@pytest.mark.parametrize("fs", [44100.0, 96000.0, 22050.0])
+@pytest.mark.parametrize("fs", [44100.0, 96000.0, 22050.0, 192000.0, 88200.0, 8000.0])
 def test_other_sample_rates(M, oracle, fs):
     T = int(fs) * 4 + 13
     x = sig.lcg_noise(T, 9, 0.5)
@@ -340,6 +340,36 @@ def test_full_size_properties(M, oracle):
         e.process_device(small.data_ptr(), T)
         o9, tp = e.out9(), e.truepeak()
     assert np.allclose(o9[:, :4], c[0][pick, :4], atol=1e-4) and np.allclose(tp, c[1][pick], rtol=1e-6)
+
+
+@pytest.mark.parametrize("chn", [1, 2])
+def test_truepeak_ballistics_many_streams(M, oracle, chn):
+    """The batch layout of k_tpb: 64 streams per workgroup (the last one partly filled), 16-frame chunks with a
+    ragged tail, three calls of odd sizes, mono and stereo engines; sampled streams against the oracle."""
+    import ctypes as C
+    from _oracle import MoTp
+    S, T = 131, 5003
+    x = np.stack([sig.lcg_noise(T, 700 + s, 2.0 ** -(s % 4)) for s in range(S)])       # [S][T][2]
+    feed = x if chn == 2 else np.ascontiguousarray(x[:, :, 0])
+    cuts = (0, 17, 2400, T)
+    with M.Engine(S, 48000.0, M.METER_TPBALLIST, n_channels=chn) as e:
+        got = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            e.process(np.ascontiguousarray(feed[:, a:b]))
+            r = e.results()
+            got.append([[(r[s].tpb_level[c], r[s].tpb_peak[c]) for c in range(chn)] for s in range(S)])
+    for s in (0, 1, 63, 64, 65, 127, 128, 130):
+        for c in range(chn):
+            ch = np.ascontiguousarray(x[s, :, c])
+            t = MoTp()
+            oracle.lib.mo_tp_init(C.byref(t), 48000.0)
+            m, p = C.c_float(), C.c_float()
+            for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                seg = np.ascontiguousarray(ch[a:b])
+                oracle.lib.mo_tp_process(C.byref(t), seg, seg.size)
+                oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
+                assert abs(got[i][s][c][0] - m.value) < 2e-6 * max(1.0, m.value), (s, c, i, got[i][s][c][0], m.value)
+                assert abs(got[i][s][c][1] - p.value) < 2e-6 * max(1.0, p.value), (s, c, i)
 
 
 def test_truepeak_ballistics_batch(M, oracle):
