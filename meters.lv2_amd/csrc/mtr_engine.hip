@@ -64,6 +64,7 @@ struct mtr_engine {
 
 	DevBuf<mtr_stream_state> state;
 	DevBuf<int32_t>  hist;
+	DevBuf<int32_t>  gate_max;      // [S][2] max-hold scratch of the multi-workgroup gate path
 	DevBuf<float>    fir_hist[2];   // ping-pong 47-frame history
 	int              hist_cur = 0;
 	DevBuf<float>    scan_m, bin_power, tile_power, frag_power, stage;
@@ -261,6 +262,12 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	    || e->fir_hist[0].reserve ((size_t) S * MTR_FIR_HALO * 2) || e->fir_hist[1].reserve ((size_t) S * MTR_FIR_HALO * 2))
 		rc = fail (MTR_ERR_NOMEM, "hipMalloc stream state");
 	if (rc == MTR_OK) rc = upload_consts (e);
+	if (rc == MTR_OK) {
+		// max-hold scratch of the multi-workgroup gate: "minus infinity" as a sortable int (mtr_gate.hip)
+		std::vector<int32_t> m ((size_t) S * 2, (int32_t) 0x807fffff);
+		if (e->gate_max.reserve (m.size ())) rc = fail (MTR_ERR_NOMEM, "hipMalloc gate scratch");
+		else if (hipMemcpy (e->gate_max.p, m.data (), m.size () * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail (MTR_ERR_HIP, "hipMemcpy gate scratch");
+	}
 	if (rc == MTR_OK && (cfg->meters & MTR_METER_SPECTR30)) {
 		std::vector<double> c (MTR_NBANDS * 6 * 5);
 		for (uint32_t b = 0; b < MTR_NBANDS; ++b) {
@@ -535,6 +542,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ga.n_streams = S; ga.n_tiles = ebu ? pl.n_tiles : 0; ga.n_frag = ebu ? pl.n_frag : 0;
 		ga.tail_tile = ebu ? pl.tail_tile : 0;
 		ga.fragm = (float) e->fragm; ga.integr = e->integr ? 1 : 0;
+		ga.max_scratch = e->gate_max.p;
 		if (mtr_launch_gate (ga, st)) return fail (MTR_ERR_HIP, "k_gate launch");
 		e->last_n_frag = ga.n_frag;
 		e->frcnt = pl.frcnt_out;

@@ -205,8 +205,174 @@ __global__ __launch_bounds__ (256) void k_gate (const mtr_gate_args a)
 	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) ghist[i] = (&sh_hist[0][0])[i];
 }
 
+// ---- long calls: the same bookkeeping spread over many workgroups per stream ----------------------------
+//
+// One workgroup walking 72 000 fragments (an hour of audio in one call) takes 0.7 ms — twice the K-weighting
+// kernel itself.  Nothing in the reference's per-fragment work is order dependent except the single
+// calc_integ / calc_range evaluation that survives (at fragment f_calc, within the last ten of the call):
+// histogram inserts are integer counts, the max-hold is a max.  So:
+//   k_gate_frag   grid (blocks, streams): fragments [b FPB, (b+1) FPB): powers (with 63 fragments of history
+//                 recomputed), M / S, inserts for f <= f_calc into an LDS histogram flushed with global
+//                 atomics, block maxima with atomicMax on sortable ints, the optional fragment-power output;
+//   k_gate_final  one workgroup per stream, after it: calc_* on the merged histogram, the <= 9 inserts after
+//                 f_calc, the values a getter sees, the 64-fragment ring and the counters for the next call.
+// Every number is the one k_gate produces (tests/test_gpu_parity.py: one long call == many short ones).
+#define GATE_FPB 1024
+
+__device__ __forceinline__ int32_t sortable (float v) { const int32_t b = __float_as_int (v); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float unsortable (int32_t k) { return __int_as_float (k ^ ((k >> 31) & 0x7fffffff)); }
+
+// mean power of fragment f of this call (f < 0: history of earlier calls from the ring)
+__device__ __forceinline__ float frag_power_of (const mtr_gate_args& a, const mtr_stream_state* st, const float* tp, int f)
+{
+	if (f < 0) return f >= -64 ? st->ring[64 + f] : 0.f;
+	float acc = (f == 0) ? st->frpwr : 1e-30f;
+	for (uint32_t j = a.frag_tile[f]; j < a.frag_tile[f + 1]; ++j) acc += tp[j];
+	return divf_cr (acc, a.fragm);
+}
+
+__device__ __forceinline__ int gate_f_calc (const mtr_gate_args& a, int div2_0)
+{
+	if (!a.integr || a.n_frag == 0) return -1;
+	const int r = (div2_0 + (int) a.n_frag) % 10;          // _div2 after the last fragment
+	const int f = (int) a.n_frag - 1 - r;
+	return f >= 0 ? f : -1;
+}
+
+__global__ __launch_bounds__ (256) void k_gate_frag (const mtr_gate_args a)
+{
+#pragma clang fp contract(off)
+	__shared__ float   pw[64 + GATE_FPB];
+	__shared__ int32_t sh_hist[2][MTR_HIST_LEN];
+	__shared__ int32_t sh_cnt[4];
+	const uint32_t s = blockIdx.y;
+	const int tid = threadIdx.x;
+	const int f0 = (int) blockIdx.x * GATE_FPB;
+	const int nf = min ((int) a.n_frag - f0, GATE_FPB);
+	if (nf <= 0) return;
+	mtr_stream_state* const st = a.state + s;
+	const float* const tp = a.tile_power + (size_t) s * a.n_tiles;
+	const int div1_0 = st->div1, div2_0 = st->div2;
+	const int f_calc = gate_f_calc (a, div2_0);
+	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) (&sh_hist[0][0])[i] = 0;
+	if (tid < 4) sh_cnt[tid] = 0;
+	for (int i = tid; i < 64 + nf; i += 256) {
+		const int f = f0 - 64 + i;
+		const float p = frag_power_of (a, st, tp, f);
+		pw[i] = p;
+		if (f >= f0 && a.frag_power) a.frag_power[(size_t) s * a.n_frag + f] = p;
+	}
+	__syncthreads ();
+	float mxM = -INFINITY, mxS = -INFINITY;
+	for (int i = tid; i < nf; i += 256) {
+		const int f = f0 + i;
+		float lm = addfrags (&pw[64 + i], 8), ls = addfrags (&pw[64 + i], 60);
+		if (!isfinite (lm) || lm < -200.f) lm = -200.0f;
+		if (!isfinite (ls) || ls < -200.f) ls = -200.0f;
+		mxM = lm > mxM ? lm : mxM;
+		mxS = ls > mxS ? ls : mxS;
+		if (a.integr && f <= f_calc) {
+			if ((div1_0 + f + 1) % 2 == 0)  hist_add (sh_hist[0], &sh_cnt[0], &sh_cnt[2], lm);
+			if ((div2_0 + f + 1) % 10 == 0) hist_add (sh_hist[1], &sh_cnt[1], &sh_cnt[3], ls);
+		}
+	}
+	for (int d = 32; d >= 1; d >>= 1) {
+		mxM = fmaxf (mxM, __shfl_xor (mxM, d, 64));
+		mxS = fmaxf (mxS, __shfl_xor (mxS, d, 64));
+	}
+	if ((tid & 63) == 0 && mxM > -INFINITY) {
+		atomicMax (&a.max_scratch[2 * s], sortable (mxM));
+		atomicMax (&a.max_scratch[2 * s + 1], sortable (mxS));
+	}
+	__syncthreads ();
+	int32_t* const ghist = a.hist + (size_t) s * 2 * MTR_HIST_LEN;
+	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) {
+		const int32_t c = (&sh_hist[0][0])[i];
+		if (c) atomicAdd (&ghist[i], c);
+	}
+	if (tid == 0) {
+		if (sh_cnt[0]) atomicAdd (&st->cnt_M, sh_cnt[0]);
+		if (sh_cnt[1]) atomicAdd (&st->cnt_S, sh_cnt[1]);
+		if (sh_cnt[2]) atomicAdd (&st->err_M, sh_cnt[2]);
+		if (sh_cnt[3]) atomicAdd (&st->err_S, sh_cnt[3]);
+	}
+}
+
+__global__ __launch_bounds__ (256) void k_gate_final (const mtr_gate_args a)
+{
+#pragma clang fp contract(off)
+	__shared__ float   pw[192];                 // powers of fragments n_frag - 192 .. n_frag - 1, chronological
+	__shared__ int32_t sh_hist[2][MTR_HIST_LEN];
+	__shared__ int32_t sh_cnt[4];
+	const uint32_t s = blockIdx.x;
+	const int tid = threadIdx.x;
+	mtr_stream_state* const st = a.state + s;
+	const float* const tp = a.tile_power + (size_t) s * a.n_tiles;
+	int32_t* const ghist = a.hist + (size_t) s * 2 * MTR_HIST_LEN;
+	const int n = (int) a.n_frag;
+	const int div1_0 = st->div1, div2_0 = st->div2;
+	const int f_calc = gate_f_calc (a, div2_0);
+	if (tid < 192) pw[tid] = frag_power_of (a, st, tp, n - 192 + tid);
+	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) (&sh_hist[0][0])[i] = ghist[i];
+	if (tid < 4) sh_cnt[tid] = (tid == 0) ? st->cnt_M : (tid == 1) ? st->cnt_S : (tid == 2) ? st->err_M : st->err_S;
+	__syncthreads ();
+	if (f_calc >= 0) {
+		if (tid == 0)       hist_calc_integ (sh_hist[0], sh_cnt[0], a.bin_power, &st->integ, &st->integ_thr);
+		else if (tid == 64) hist_calc_range (sh_hist[1], sh_cnt[1], a.bin_power, &st->rmin, &st->rmax, &st->rthr);
+	}
+	__syncthreads ();
+	if (tid == 0) {
+		// the fragments after f_calc (at most nine) and the values a getter sees
+		float last_M = st->loud_M, last_S = st->loud_S;
+		float mxM = -INFINITY, mxS = -INFINITY;
+		for (int f = max (n - 10, 0); f < n; ++f) {               // f_calc is among them; the last one always is
+			const float* newest = &pw[191 - (n - 1 - f)];
+			float lm = addfrags (newest, 8), ls = addfrags (newest, 60);
+			if (!isfinite (lm) || lm < -200.f) lm = -200.0f;
+			if (!isfinite (ls) || ls < -200.f) ls = -200.0f;
+			if (a.integr && f > f_calc) {
+				if ((div1_0 + f + 1) % 2 == 0)  hist_add (sh_hist[0], &sh_cnt[0], &sh_cnt[2], lm);
+				if ((div2_0 + f + 1) % 10 == 0) hist_add (sh_hist[1], &sh_cnt[1], &sh_cnt[3], ls);
+			}
+			if (f == n - 1) { last_M = lm; last_S = ls; }
+			mxM = lm > mxM ? lm : mxM;
+			mxS = ls > mxS ? ls : mxS;
+		}
+		const float bM = unsortable (a.max_scratch[2 * s]), bS = unsortable (a.max_scratch[2 * s + 1]);
+		float max_M = st->max_M, max_S = st->max_S;
+		max_M = bM > max_M ? bM : max_M;
+		max_S = bS > max_S ? bS : max_S;
+		a.max_scratch[2 * s] = sortable (-INFINITY);
+		a.max_scratch[2 * s + 1] = sortable (-INFINITY);
+		float acc = (n == 0) ? st->frpwr : 1e-30f;
+		for (uint32_t j = a.tail_tile; j < a.n_tiles; ++j) acc += tp[j];
+		st->frpwr = acc;
+		st->loud_M = last_M; st->loud_S = last_S;
+		st->max_M = max_M;   st->max_S = max_S;
+		st->div1 = a.integr ? (div1_0 + n) % 2 : div1_0;
+		st->div2 = a.integr ? (div2_0 + n) % 10 : div2_0;
+		st->cnt_M = sh_cnt[0]; st->cnt_S = sh_cnt[1]; st->err_M = sh_cnt[2]; st->err_S = sh_cnt[3];
+		const float cl = __uint_as_float (st->tp_call[0]), cr = __uint_as_float (st->tp_call[1]);
+		st->tp_last[0] = cl; st->tp_last[1] = cr;
+		if (cl > st->tp_hold[0]) st->tp_hold[0] = cl;
+		if (cr > st->tp_hold[1]) st->tp_hold[1] = cr;
+		st->tp_call[0] = 0; st->tp_call[1] = 0;
+	}
+	__syncthreads ();
+	// only the bins the late inserts touched differ from the global histogram: write all back
+	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) ghist[i] = (&sh_hist[0][0])[i];
+	if (tid < 64) st->ring[tid] = pw[128 + tid];
+}
+
 int mtr_launch_gate (const mtr_gate_args& a, void* stream)
 {
+	// many fragments per call and few streams: spread a stream over several workgroups
+	if (a.n_frag >= 4 * GATE_FPB && a.max_scratch) {
+		const uint32_t nb = (a.n_frag + GATE_FPB - 1) / GATE_FPB;
+		hipLaunchKernelGGL (k_gate_frag, dim3 (nb, a.n_streams), dim3 (256), 0, (hipStream_t) stream, a);
+		hipLaunchKernelGGL (k_gate_final, dim3 (a.n_streams), dim3 (256), 0, (hipStream_t) stream, a);
+		return hipGetLastError () == hipSuccess ? 0 : -1;
+	}
 	hipLaunchKernelGGL (k_gate, dim3 (a.n_streams), dim3 (256), 0, (hipStream_t) stream, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }

@@ -61,6 +61,7 @@ struct mtr_gate_args {
 	uint32_t        tail_tile;    /* first tile after the last complete fragment (tiles of the open fragment) */
 	float           fragm;        /* frames per fragment, as float */
 	int32_t         integr;       /* integration on? */
+	int32_t*        max_scratch;  /* [S][2] max-hold of M / S as sortable ints, for the multi-workgroup path */
 };
 
 struct mtr_bank_args {

@@ -342,6 +342,44 @@ def test_full_size_properties(M, oracle):
     assert np.allclose(o9[:, :4], c[0][pick, :4], atol=1e-4) and np.allclose(tp, c[1][pick], rtol=1e-6)
 
 
+@pytest.mark.parametrize("meters", ["ebu", "ebu+tp"])
+def test_long_call_gate_spread_over_workgroups(M, oracle, meters):
+    """>= 4096 fragments in one call take the multi-workgroup gate (k_gate_frag + k_gate_final): same record,
+    histograms and fragment powers as the oracle, and as the same audio fed in short calls (single-workgroup path)."""
+    fs = 48000.0
+    T = int(fs) * 215 + 1234                                  # 4300 fragments
+    x = np.stack([sig.lcg_noise(T, 91 + s, 0.25 * (s + 1)) for s in range(2)])
+    env = (0.1 + 0.9 * ((np.arange(T) // 240000) % 3 == 0)).astype(np.float32)      # loud / quiet alternation: gating matters
+    x = (x * env[None, :, None]).astype(np.float32)
+    mask = M.METER_EBU | (M.METER_TRUEPEAK if meters == "ebu+tp" else 0)
+
+    def run(cuts):
+        # one time segment per stream and calls cut on fragment boundaries: both runs see the same tiles and the
+        # same carried K-filter state, so everything downstream must be bit-identical
+        with M.Engine(2, fs, mask, tune_segments=1) as e:
+            e.integr_start()
+            frags = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                e.process(np.ascontiguousarray(x[:, a:b]))
+                frags.append(e.fragment_powers())
+            hm, hs = e.histograms()
+            return e.out9(), np.concatenate(frags, 1), hm, hs, e.results()
+
+    one = run([0, T])
+    many = run(list(range(0, T, 2400 * 400)) + [T])           # 11 calls of 400 fragments: the single-workgroup gate
+    assert np.array_equal(one[1], many[1])                    # fragment powers do not depend on the call pattern here
+    assert np.array_equal(one[2], many[2]), np.flatnonzero(one[2] != many[2])[:8]
+    assert np.array_equal(one[3], many[3]), np.flatnonzero(one[3] != many[3])[:8]
+    assert np.array_equal(one[0], many[0]), (one[0], many[0])
+    for s in range(2):
+        o = oracle.ebu(x[s], fs, 4096, want_frag=True)
+        assert np.allclose(one[1][s], o["frag_power"], rtol=2e-5)
+        assert np.allclose(one[0][s, :4], o["out9"][:4], atol=DB_TOL)
+        assert abs(one[0][s, 4] - o["out9"][4]) <= 0.01 and abs(one[0][s, 6] - o["out9"][6]) <= 0.1001
+        assert np.abs(one[2][s] - o["hist_M"]).sum() <= 6 and np.abs(one[3][s] - o["hist_S"]).sum() <= 4
+        assert (one[4][s].hist_M_count, one[4][s].hist_S_count) == tuple(o["counts"])
+
+
 @pytest.mark.parametrize("chn", [1, 2])
 def test_truepeak_ballistics_many_streams(M, oracle, chn):
     """The batch layout of k_tpb: 64 streams per workgroup (the last one partly filled), 16-frame chunks with a
