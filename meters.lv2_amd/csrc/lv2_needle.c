@@ -252,3 +252,84 @@ void kmeter_run (LV2_Handle h, uint32_t n_samples)  /* :333-412 */
 }
 
 void needle_cleanup (LV2_Handle h) { free (h); }
+
+/* ======================================================================================
+ * surround3 .. surround8 (src/surmeter.c): a K-meter per channel (level + peak) and up to four
+ * correlation meters whose input pairs are chosen on control ports.  Ports: 0 reference level,
+ * 1..12 = four x (channel a, channel b, correlation out), then per channel in, out, level, peak.
+ * ====================================================================================== */
+#define SUR_MAXCH 8
+typedef struct {
+	uint32_t chn;
+	float* reflvl;
+	float* surc_a[4];
+	float* surc_b[4];
+	float* surc_c[4];
+	float* input[SUR_MAXCH];
+	float* output[SUR_MAXCH];
+	float* level[SUR_MAXCH];
+	float* peak[SUR_MAXCH];
+	Kmeter km[SUR_MAXCH];
+	Cor cor4[4];
+} Surround;
+
+LV2_Handle sur_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features)
+{
+	(void) path; (void) features;
+	const size_t l = sizeof (MTR_URI "surround") - 1;
+	if (strncmp (d->URI, MTR_URI "surround", l) || d->URI[l] < '3' || d->URI[l] > '8' || d->URI[l + 1]) return NULL;
+	Surround* self = (Surround*) calloc (1, sizeof (Surround));
+	if (!self) return NULL;
+	self->chn = (uint32_t) (d->URI[l] - '0');
+	for (uint32_t c = 0; c < self->chn; ++c) km_init (&self->km[c], (float) rate);
+	for (uint32_t c = 0; c < 4; ++c) {                        /* Stcorrdsp::init (rate, 2e3f, 0.3f), surmeter.c:64-67 */
+		self->cor4[c].w1 = 6.28f * 2e3f / (int) rate;
+		self->cor4[c].w2 = 1 / (0.3f * (int) rate);
+	}
+	return self;
+}
+
+void sur_connect_port (LV2_Handle h, uint32_t port, void* data)   /* surmeter.c:74-113 */
+{
+	Surround* self = (Surround*) h;
+	if (port == 0) {
+		self->reflvl = (float*) data;
+	} else if (port <= 12) {
+		const int cor = (port - 1) / 3;
+		switch (port % 3) {
+		case 1: self->surc_a[cor] = (float*) data; break;
+		case 2: self->surc_b[cor] = (float*) data; break;
+		default: self->surc_c[cor] = (float*) data; break;
+		}
+	} else if (port <= 12 + 4 * self->chn) {
+		const int chan = (port - 13) / 4;
+		switch (port % 4) {
+		case 1: self->input[chan] = (float*) data; break;
+		case 2: self->output[chan] = (float*) data; break;
+		case 3: self->level[chan] = (float*) data; break;
+		default: self->peak[chan] = (float*) data; break;
+		}
+	}
+}
+
+void sur_run (LV2_Handle h, uint32_t n_samples)               /* surmeter.c:115-144 */
+{
+	Surround* self = (Surround*) h;
+	const uint32_t cors = self->chn > 3 ? 4 : 3;
+	for (uint32_t c = 0; c < cors; ++c) {
+		uint32_t in_a = rintf (*self->surc_a[c]);
+		uint32_t in_b = rintf (*self->surc_b[c]);
+		if (in_a >= self->chn) in_a = self->chn - 1;
+		if (in_b >= self->chn) in_b = self->chn - 1;
+		cor_process (&self->cor4[c], self->input[in_a], self->input[in_b], (int) n_samples);
+		*self->surc_c[c] = self->cor4[c].zlr / sqrtf (self->cor4[c].zll * self->cor4[c].zrr + 1e-10f);
+	}
+	for (uint32_t c = 0; c < self->chn; ++c) {
+		float m, p;
+		km_process (&self->km[c], self->input[c], (int) n_samples);
+		km_read (&self->km[c], &m, &p);
+		*self->level[c] = m;
+		*self->peak[c] = p;
+		if (self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
+	}
+}

@@ -15,6 +15,7 @@
  *   8      bitmeter        src/bitmeter.c (lv2_intstat.c)   — IEEE-754 bit statistics on the GPU, UI protocol + State
  *   9-24   BBC / EBU / DIN / NOR mono+stereo, COR, BBCM6, K12 / K14 / K20 mono+stereo (lv2_needle.c) — CPU plumbing
  *   25-28  dr14mono/stereo, TPnRMSmono/stereo   src/dr14.c (lv2_dr14.c) — true-peak ballistics on the GPU
+ *   29-34  surround8 .. surround3               src/surmeter.c (lv2_needle.c) — CPU plumbing
  *
  * The reference enumerates 38 plugins (src/meters.cc:745-792); LV2 hosts match by URI and stop at
  * the first NULL, so the in-scope subset is enumerated densely.
@@ -334,6 +335,9 @@ static const LV2_Descriptor descriptors[] = {
 #define DR14(name) { MTR_URI name, dr14_instantiate, dr14_connect_port, NULL, dr14_run, NULL, dr14_cleanup, no_extension }
 	DR14 ("dr14mono"), DR14 ("dr14stereo"), DR14 ("TPnRMSmono"), DR14 ("TPnRMSstereo"),
 #undef DR14
+#define SUR(name) { MTR_URI name, sur_instantiate, sur_connect_port, NULL, sur_run, NULL, needle_cleanup, no_extension }
+	SUR ("surround8"), SUR ("surround7"), SUR ("surround6"), SUR ("surround5"), SUR ("surround4"), SUR ("surround3"),
+#undef SUR
 };
 
 LV2_SYMBOL_EXPORT const LV2_Descriptor* lv2_descriptor (uint32_t index)

@@ -30,6 +30,9 @@ void        cor_run (LV2_Handle h, uint32_t n_samples);
 void        bbcm_run (LV2_Handle h, uint32_t n_samples);
 void        kmeter_run (LV2_Handle h, uint32_t n_samples);
 void        needle_cleanup (LV2_Handle h);
+LV2_Handle  sur_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features);
+void        sur_connect_port (LV2_Handle h, uint32_t port, void* data);
+void        sur_run (LV2_Handle h, uint32_t n_samples);
 
 /* lv2_dr14.c — src/dr14.c: DR-14 and true-peak + RMS */
 LV2_Handle  dr14_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features);

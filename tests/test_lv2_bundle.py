@@ -20,7 +20,8 @@ def test_ttl_matches_the_plugin_port_maps(tmp_path):
     want = {"VUmono": 4, "VUstereo": 7, "EBUr128": 6, "spectr30mono": 66, "dBTPmono": 5, "dBTPstereo": 9,
             "spectr30stereo": 68, "SigDistHist": 4, "bitmeter": 4}
     needles = {"BBCmono": 4, "EBUstereo": 7, "DINmono": 4, "NORstereo": 7, "COR": 6, "BBCM6": 8, "K14mono": 6, "K20stereo": 10,
-               "dr14mono": 11, "dr14stereo": 19, "TPnRMSmono": 11, "TPnRMSstereo": 19}
+               "dr14mono": 11, "dr14stereo": 19, "TPnRMSmono": 11, "TPnRMSstereo": 19,
+               "surround3": 25, "surround5": 33, "surround8": 45}
     for p, n in needles.items():
         assert f"mtr:{p}\n" in man
         blk = ttl.split(f"mtr:{p}\n")[1].split("\n\t.\n")[0]

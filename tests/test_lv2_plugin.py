@@ -12,7 +12,8 @@ IN_SCOPE = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPst
             "SigDistHist", "bitmeter",
             "BBCmono", "BBCstereo", "EBUmono", "EBUstereo", "DINmono", "DINstereo", "NORmono", "NORstereo", "COR", "BBCM6",
             "K12mono", "K14mono", "K20mono", "K12stereo", "K14stereo", "K20stereo",
-            "dr14mono", "dr14stereo", "TPnRMSmono", "TPnRMSstereo"]
+            "dr14mono", "dr14stereo", "TPnRMSmono", "TPnRMSstereo",
+            "surround8", "surround7", "surround6", "surround5", "surround4", "surround3"]
 
 
 @pytest.fixture(scope="module")

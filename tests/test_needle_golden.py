@@ -184,3 +184,37 @@ def test_plugins_match_the_reference_vectors(host, fs):
     inst.run(B)
     assert hold[0] <= -1.0
     inst.cleanup()
+
+
+@pytest.mark.parametrize("chn", [3, 5, 8])
+def test_surround_meters_match_the_reference_vectors(host, chn):
+    """surroundN (src/surmeter.c): a K-meter per channel and correlation meters over selectable channel pairs —
+    the same DSP objects as K20mono and COR, so the same golden sequences must come out of the ports."""
+    from _lv2host import Instance
+    fs, tag = 48000.0, "48000"
+    xl, xr = signal()
+    blocks = list(range(0, xl.size - B + 1, B))
+    inst = Instance(host, "surround%d" % chn, rate=fs)
+    assert inst.ok()
+    inst.connect(0, _f(-18.0))
+    cors = 4 if chn > 3 else 3
+    sel_a, sel_b, cor = [_f(0.0) for _ in range(4)], [_f(1.0) for _ in range(4)], [_f() for _ in range(4)]
+    sel_a[1][0], sel_b[1][0] = 1.0, 99.0                      # second meter: (R, clamped to the last channel)
+    for c in range(4):
+        inst.connect(1 + 3 * c, sel_a[c]); inst.connect(2 + 3 * c, sel_b[c]); inst.connect(3 + 3 * c, cor[c])
+    lv, pk = [_f() for _ in range(chn)], [_f() for _ in range(chn)]
+    for c in range(chn):
+        inst.connect(13 + 4 * c + 2, lv[c]); inst.connect(13 + 4 * c + 3, pk[c])
+    seq_k, seq_c = [], []
+    for q in blocks:
+        bufs = [(xl if c % 2 == 0 else xr)[q:q + B].copy() for c in range(chn)]   # even channels = L, odd = R
+        for c in range(chn):
+            inst.connect(13 + 4 * c, bufs[c]); inst.connect(13 + 4 * c + 1, bufs[c])
+        inst.run(B)
+        seq_k.append((lv[0][0], pk[0][0]))
+        seq_c.append(cor[0][0])
+        assert lv[2][0] == lv[0][0] and pk[2][0] == pk[0][0]   # channel 2 carries L as well
+    assert np.array_equal(bits(seq_k), bits(G[f"kmeter_{tag}"]))
+    assert np.array_equal(bits(seq_c), bits(G[f"stcorr_{tag}"]))   # meter 0 = (channel 0, channel 1) = (L, R)
+    assert cors == 3 or np.isfinite(cor[3][0])
+    inst.cleanup()

@@ -110,6 +110,27 @@ def needles():
 
 
 DR14S = ["dr14mono", "dr14stereo", "TPnRMSmono", "TPnRMSstereo"]
+SURS = ["surround%d" % n for n in (8, 7, 6, 5, 4, 3)]
+
+
+def surrounds():
+    """src/surmeter.c:74-113: port 0 reference level, 1..12 = four x (channel a, channel b, correlation out),
+    then per channel in, out, level, peak."""
+    t = ""
+    for n in SURS:
+        chn = int(n[-1])
+        ports = [ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, -18.0)]
+        for c in range(4):
+            ports += [ctl(1 + 3 * c, "cor%da" % c, "Correlation %d channel A" % c, "Input", 0, chn - 1, min(2 * c, chn - 1)),
+                      ctl(2 + 3 * c, "cor%db" % c, "Correlation %d channel B" % c, "Input", 0, chn - 1, min(2 * c + 1, chn - 1)),
+                      ctl(3 + 3 * c, "cor%d" % c, "Correlation %d" % c, "Output", -1.0, 1.0)]
+        for c in range(chn):
+            b = 13 + 4 * c
+            ports += [audio(b, "in%d" % c, "In %d" % c, "Input"), audio(b + 1, "out%d" % c, "Out %d" % c, "Output"),
+                      ctl(b + 2, "level%d" % c, "Level %d" % c, "Output", 0.0, 2.0),
+                      ctl(b + 3, "peak%d" % c, "Peak %d" % c, "Output", 0.0, 2.0)]
+        t += plugin(n, "Surround Meter (%d channels, MI355X build)" % chn, "K-meter per channel and pairwise correlation; host CPU.", ports)
+    return t
 
 
 def dr14s():
@@ -142,7 +163,7 @@ def dr14s():
 def main(out):
     os.makedirs(out, exist_ok=True)
     plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
-             "SigDistHist", "bitmeter"] + NEEDLES + DR14S
+             "SigDistHist", "bitmeter"] + NEEDLES + DR14S + SURS
     man = PREFIX + "".join("mtr:%s\n\ta lv2:Plugin ;\n\tlv2:binary <meters_amd.so> ;\n\trdfs:seeAlso <meters_amd.ttl> .\n\n" % p
                            for p in plugs)
     open(os.path.join(out, "manifest.ttl"), "w").write(man)
@@ -187,6 +208,7 @@ def main(out):
                     extra="\tlv2:requiredFeature urid:map ;\n")
     t += needles()
     t += dr14s()
+    t += surrounds()
     open(os.path.join(out, "meters_amd.ttl"), "w").write(t)
     print("wrote", out)
 
