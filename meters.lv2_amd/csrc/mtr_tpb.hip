@@ -63,11 +63,17 @@ __device__ __forceinline__ void interpolate (const v2f* xs, cfloat_p pmq, v2f* o
 	v2f aS[R], aD[R], aQ[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) { aS[r] = 0; aD[r] = 0; aQ[r] = 0; }
+	// this kernel is latency-bound (two or three waves per SIMD): the next group's taps are fetched while
+	// the current group is computed
+	float tp[G], tm[G], tq[G];
+#pragma unroll
+	for (int k = 0; k < G; ++k) { tp[k] = pmq[k]; tm[k] = pmq[24 + k]; tq[k] = pmq[48 + k]; }
 #pragma unroll 1
 	for (int g = 0; g < 24; g += G) {
-		float tp[G], tm[G], tq[G];
+		float np[G], nm[G], nq[G];
+		const int gn = g + G < 24 ? g + G : 0;
 #pragma unroll
-		for (int k = 0; k < G; ++k) { tp[k] = pmq[g + k]; tm[k] = pmq[24 + g + k]; tq[k] = pmq[48 + g + k]; }
+		for (int k = 0; k < G; ++k) { np[k] = pmq[gn + k]; nm[k] = pmq[24 + gn + k]; nq[k] = pmq[48 + gn + k]; }
 		const v2f* const xl = xs + 1 + g;
 		const v2f* const xr = xs + 48 - g - (G - 1);
 		v2f L[R + G - 1], B[R + G - 1];
@@ -84,6 +90,8 @@ __device__ __forceinline__ void interpolate (const v2f* xs, cfloat_p pmq, v2f* o
 				aQ[r] += tq[k] * sv;
 			}
 		}
+#pragma unroll
+		for (int k = 0; k < G; ++k) { tp[k] = np[k]; tm[k] = nm[k]; tq[k] = nq[k]; }
 	}
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
