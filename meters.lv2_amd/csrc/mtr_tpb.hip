@@ -13,18 +13,23 @@
 // (first version: one wave per stream, one lane walking 256 values per 64 frames: 543 ms per
 // 31.5 GB; this one: see DESIGN.md):
 //
-//   * a workgroup of nine waves owns 64 streams, lane = stream, both channels packed in one v2f;
-//   * waves 0-7 interpolate: each takes 2 of the chunk's 16 frames for all 64 streams (mirror-
-//     symmetric taps as in k_fused2, held in VGPRs) and leaves |y| of the 4 phases in LDS in time
-//     order; they also fetch the next chunk's input rows (one coalesced load per stream row, all
-//     of them unconditional: a load inside a divergent branch is waited for on the spot);
-//   * wave 8 is the recurrence: 64 independent (z1, z2, m, p) chains, 4 steps per frame, on the
-//     previous chunk's values;
-//   * both LDS arrays are double buffered; one barrier per chunk.  Input rows are re-fetched with
-//     their 48-frame history every chunk (L2 hits; HBM sees each frame once).
-// The kernel is latency-bound by construction (one workgroup per CU, the chain is serial): what
-// matters is the length of the longest role per chunk, hence many narrow interpolator waves.
-// Lane strides in LDS are odd (65 slots): every ds_read_b64 / ds_write_b64 is conflict free.
+//   * a workgroup of eight waves owns 64 streams, lane = stream, both channels packed in one v2f;
+//   * wave 0 is the recurrence: 64 independent (z1, z2, m, p) chains, 4 steps per frame, on the
+//     previous chunk's values.  It is the serial chain, so it keeps a SIMD to itself (the wave's
+//     SIMD id is read from HW_ID; the wave that shares it only fetches);
+//   * the six waves on the other three SIMDs interpolate: each takes 2 of the chunk's 12 frames for
+//     all 64 streams (mirror-symmetric form as in k_fused2; the 72 taps stay in vector registers,
+//     two per register pair) and leaves |y| of the 4 phases in LDS in time order;
+//   * waves 1-7 fetch: only the 12 new frames of every row per chunk, into a ring of six chunks per
+//     stream in which every frame is stored twice, 72 slots apart, so that the interpolator's
+//     60-slot window is always contiguous (12 wave-wide loads per chunk instead of the 70 the first
+//     version needed to re-read every row with its window — issuing those took as long as the
+//     interpolation).  All loads are unconditional: one inside a divergent branch is waited for at
+//     the end of its branch;
+//   * the |y| array is double buffered; one barrier per chunk.
+// One workgroup per CU and a serial chain: the kernel is bound by the busiest SIMD per chunk
+// (tools/tpb_prof.hip prints cycles per role: two interpolators ~3300 of the chunk's ~4100 cycles,
+// the recurrence ~3000).  Lane strides in LDS are odd (145 and 49 slots): conflict-free ds_read/write_b64.
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -32,17 +37,33 @@
 typedef float v2f __attribute__ ((ext_vector_type (2)));
 typedef const __attribute__ ((address_space (4))) float* cfloat_p;
 
+// tools/tpb_prof.hip builds this file with MTR_TPB_PROF: cycles per role and section for workgroup 0
+#ifdef MTR_TPB_PROF
+__device__ unsigned long long g_tpb_prof[16][4];
+#define PROF_NOW(v) unsigned long long v; asm volatile ("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define PROF_ADD(i, d) pr[i] += (d)
+#else
+#define PROF_NOW(v)
+#define PROF_ADD(i, d)
+#endif
+
 namespace {
 
-constexpr int NFIR = 8;                  // interpolator waves; wave NFIR is the recurrence
-constexpr int R = 2;                     // frames per interpolator wave and chunk
-constexpr int F = NFIR * R;              // 16 frames per chunk
+constexpr int NW = 8;                    // waves: wave 0 is the recurrence, the others fetch and interpolate
+constexpr int R = 2;                     // frames per interpolation item
+constexpr int NGRP = 6;                  // items per chunk: one per interpolator wave when two waves share a SIMD
+constexpr int F = NGRP * R;              // 12 frames per chunk
 constexpr int NS = 64;                   // streams per workgroup
-constexpr int IN_SLOTS = F + 48;         // 64: slot i of a row <-> frame c0 - 48 + i, one slot per lane when a row is fetched
-constexpr int IN_STRIDE = IN_SLOTS + 1;  // 65
-constexpr int OV_STRIDE = 4 * F + 1;     // 65 slots: slot 4 f + q <-> phase q of frame c0 + f
-constexpr int NTHREADS = 64 * (NFIR + 1);
-static_assert (IN_STRIDE % 2 == 1 && OV_STRIDE % 2 == 1 && IN_SLOTS == 64 && NS % NFIR == 0, "odd lane strides; a lane per slot");
+// Input rows live in a ring of six chunks per stream: the 48-frame window (four chunks) of the chunk being
+// interpolated, that chunk, and the one being fetched.  Every frame is stored twice, RING slots apart, so
+// any 60-slot window is contiguous in LDS and the interpolator's offsets stay compile-time constants.
+constexpr int RING = 6 * F;              // 72 slots; frame f <-> slot f mod 72 (and + 72)
+constexpr int IN_STRIDE = 2 * RING + 1;  // 145
+constexpr int OV_STRIDE = 4 * F + 1;     // 49 slots: slot 4 f + q <-> phase q of frame c0 + f
+constexpr int NTHREADS = 64 * NW;
+constexpr int NLOAD = NS * F / 64;       // 12 wave-wide loads bring one chunk of all 64 rows
+constexpr int LPW = (NLOAD + NW - 2) / (NW - 1);   // at most 2 of them per fetching wave
+static_assert (IN_STRIDE % 2 == 1 && OV_STRIDE % 2 == 1 && 48 % F == 0 && (NS * F) % 64 == 0, "odd lane strides; whole chunks of history");
 
 __device__ __forceinline__ v2f vabs (v2f v) { return v2f{fabsf (v.x), fabsf (v.y)}; }
 
@@ -54,45 +75,71 @@ __device__ __forceinline__ v2f attack (v2f z, v2f v, float w)
 }
 
 // R outputs of the three non-trivial polyphase branches in the mirror-symmetric form of k_fused2
-// (pmq = P, M, Q: 3 x 24 taps); xs = slot of frame (first output - 48); out[r] = |x0|, |y1|, |y2|, |y3|
-// Taps go through SGPRs in groups of 6 mirror pairs per branch (all 72 at once do not fit the scalar file;
-// keeping them in VGPRs instead was tried: with the unrolled groups it spills).
-__device__ __forceinline__ void interpolate (const v2f* xs, cfloat_p pmq, v2f* out)
+// (tp, tm, tq = P, M, Q: 3 x 24 taps); xs = slot of frame (first output - 48); out[r] = |x0|, |y1|, |y2|, |y3|.
+// The taps live in VGPRs here (72 of the 256 a wave may use at two waves per SIMD): fetched through the
+// scalar cache per group, as k_fused2 must, every group ends in an `s_waitcnt lgkmcnt(0)` that also drains
+// the LDS queue, and with two waves per SIMD nobody covers that bubble.  Fully unrolled, the LDS reads of
+// later groups are issued under the arithmetic of earlier ones.
+// Two taps share a register pair and the multiply picks its half (op_sel), so they cost 72 registers, not 144.
+struct Taps { v2f p[12], m[12], q[12]; };
+// (the compiler folds that selection only for scalar-register operands, hence the two asm forms)
+template <int K>
+__device__ __forceinline__ void tap_fma (v2f& acc, const v2f* t, v2f x)
 {
-	constexpr int G = 6;
+	if (K & 1) asm ("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(t[K >> 1]));
+	else       asm ("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(t[K >> 1]));
+}
+
+constexpr int G = 6;                     // mirror pairs per tap group
+constexpr int NW_G = R + G - 1;          // window slots a group needs on either side
+
+template <int G0>
+__device__ __forceinline__ void group_load (const v2f* xs, v2f* L, v2f* B)
+{
+	const v2f* const xl = xs + 1 + G0;
+	const v2f* const xr = xs + 48 - G0 - (G - 1);
+#pragma unroll
+	for (int j = 0; j < NW_G; ++j) { L[j] = xl[j]; B[j] = xr[j]; }
+}
+
+template <int G0>
+__device__ __forceinline__ void group_mac (const v2f* L, const v2f* B, const Taps& tp, v2f* aS, v2f* aD, v2f* aQ)
+{
+#define MTR_TPB_TAP(k)                                                                   \
+	{                                                                                    \
+		const v2f sv = L[r + k] + B[r + G - 1 - k];                                      \
+		const v2f dv = L[r + k] - B[r + G - 1 - k];                                      \
+		tap_fma<G0 + k> (aS[r], tp.p, sv);                                               \
+		tap_fma<G0 + k> (aD[r], tp.m, dv);                                               \
+		tap_fma<G0 + k> (aQ[r], tp.q, sv);                                               \
+	}
+#pragma unroll
+	for (int r = 0; r < R; ++r) { MTR_TPB_TAP (0) MTR_TPB_TAP (1) MTR_TPB_TAP (2) MTR_TPB_TAP (3) MTR_TPB_TAP (4) MTR_TPB_TAP (5) }
+#undef MTR_TPB_TAP
+}
+
+__device__ __forceinline__ void interpolate (const v2f* xs, const Taps& tp, v2f* out)
+{
 	v2f aS[R], aD[R], aQ[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) { aS[r] = 0; aD[r] = 0; aQ[r] = 0; }
-	// this kernel is latency-bound (two or three waves per SIMD): the next group's taps are fetched while
-	// the current group is computed
-	float tp[G], tm[G], tq[G];
-#pragma unroll
-	for (int k = 0; k < G; ++k) { tp[k] = pmq[k]; tm[k] = pmq[24 + k]; tq[k] = pmq[48 + k]; }
-#pragma unroll 1
-	for (int g = 0; g < 24; g += G) {
-		float np[G], nm[G], nq[G];
-		const int gn = g + G < 24 ? g + G : 0;
-#pragma unroll
-		for (int k = 0; k < G; ++k) { np[k] = pmq[gn + k]; nm[k] = pmq[24 + gn + k]; nq[k] = pmq[48 + gn + k]; }
-		const v2f* const xl = xs + 1 + g;
-		const v2f* const xr = xs + 48 - g - (G - 1);
-		v2f L[R + G - 1], B[R + G - 1];
-#pragma unroll
-		for (int j = 0; j < R + G - 1; ++j) { L[j] = xl[j]; B[j] = xr[j]; }
-#pragma unroll
-		for (int r = 0; r < R; ++r) {
-#pragma unroll
-			for (int k = 0; k < G; ++k) {
-				const v2f sv = L[r + k] + B[r + G - 1 - k];
-				const v2f dv = L[r + k] - B[r + G - 1 - k];
-				aS[r] += tp[k] * sv;
-				aD[r] += tm[k] * dv;
-				aQ[r] += tq[k] * sv;
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < G; ++k) { tp[k] = np[k]; tm[k] = nm[k]; tq[k] = nq[k]; }
-	}
+	// the LDS reads of a group are issued a whole group of arithmetic ahead (left to itself the scheduler
+	// sinks them next to their first use, and with two waves per SIMD that latency is not covered)
+	v2f L0[NW_G], B0[NW_G], L1[NW_G], B1[NW_G];
+	group_load<0> (xs, L0, B0);
+	group_load<6> (xs, L1, B1);
+	__builtin_amdgcn_sched_barrier (0);
+	group_mac<0> (L0, B0, tp, aS, aD, aQ);
+	__builtin_amdgcn_sched_barrier (0);
+	group_load<12> (xs, L0, B0);
+	__builtin_amdgcn_sched_barrier (0);
+	group_mac<6> (L1, B1, tp, aS, aD, aQ);
+	__builtin_amdgcn_sched_barrier (0);
+	group_load<18> (xs, L1, B1);
+	__builtin_amdgcn_sched_barrier (0);
+	group_mac<12> (L0, B0, tp, aS, aD, aQ);
+	__builtin_amdgcn_sched_barrier (0);
+	group_mac<18> (L1, B1, tp, aS, aD, aQ);
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
 		out[4 * r + 0] = vabs (xs[24 + r]);          // phase 0 is the identity: x[n - 24]
@@ -102,49 +149,81 @@ __device__ __forceinline__ void interpolate (const v2f* xs, cfloat_p pmq, v2f* o
 	}
 }
 
+template <int C>      // channels: 2 = interleaved stereo, 1 = mono (the right half of every v2f stays zero)
 __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 {
 	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-	v2f* const in_buf = reinterpret_cast<v2f*> (smem);                   // [2][NS][IN_STRIDE]
-	v2f* const ov_buf = in_buf + 2 * NS * IN_STRIDE;                     // [2][NS][OV_STRIDE]
-	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	v2f* const in_buf = reinterpret_cast<v2f*> (smem);                   // [NS][IN_STRIDE]
+	v2f* const ov_buf = in_buf + NS * IN_STRIDE;                         // [2][NS][OV_STRIDE]
+	const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
 	const uint32_t s0 = blockIdx.x * NS;
-	const int C = (int) a.n_channels;
 	const int64_t n_chunks = (int64_t) ((a.n_frames + F - 1) / F);
-	const bool fir = wid < NFIR;
+	const bool fir = wid != 0;
 
-	const cfloat_p pmq = (cfloat_p) a.fir_pmq;
+	// Role placement.  The recurrence is the serial chain of the kernel (about 40 VALU instructions per
+	// frame that nothing can overlap), so its wave gets a SIMD to itself: waves that the dispatcher put on
+	// wave 0's SIMD only fetch; the others share the interpolation items.  HW_ID bits 5:4 = SIMD.
+	__shared__ int simd_of[NW];
+	if (lane == 0) simd_of[wid] = (int) __builtin_amdgcn_s_getreg ((1 << 11) | (4 << 6) | 4);
+	__syncthreads ();
+	int item0 = -1, n_interp = 0;
+	for (int w = 1; w < NW; ++w) {
+		const bool other = simd_of[w] != simd_of[0];
+		if (w == wid && other) item0 = n_interp;
+		n_interp += other;
+	}
+	if (n_interp < 3) { item0 = wid - 1; n_interp = NW - 1; }          // unexpected placement: everyone interpolates
+	item0 = __builtin_amdgcn_readfirstlane (item0);
+	n_interp = __builtin_amdgcn_readfirstlane (n_interp);
 
-	// ---- interpolator waves: fetch the rows of chunk j (64 rows shared out over the NFIR waves) ----
-	constexpr int ROWS = NS / NFIR;                                      // 8 rows per wave
-	const int row0 = wid * ROWS;
-	// Every load is unconditional (addresses clamped into the stream, the mask applied when the value is
-	// stored): a load inside a divergent branch is waited for at the end of its branch, and 22 global
-	// latencies in series per chunk was the whole run time of the first attempt (it did not even depend
-	// on the number of streams).
-	auto fetch = [&] (int64_t j, v2f (&v)[ROWS]) {
-		const int64_t f = j * F - 48 + lane;                             // lane <-> slot: frame of this call (f < 0: history)
-		const bool in_hist = f < 0;
-		const int64_t fc = f < 0 ? 0 : (f < (int64_t) a.n_frames ? f : (int64_t) a.n_frames - 1);
-		const int64_t hc = f < -MTR_FIR_HALO ? 0 : (f < 0 ? MTR_FIR_HALO + f : 0);
+	Taps taps;
+	if (fir) {
+		const cfloat_p pmq = (cfloat_p) a.fir_pmq;
 #pragma unroll
-		for (int r = 0; r < ROWS; ++r) {
-			uint32_t s = s0 + (uint32_t) (row0 + r);
-			s = s < a.n_streams ? s : s0;
-			const float* const p = in_hist ? a.hist + ((size_t) s * MTR_FIR_HALO + (size_t) hc) * 2
-			                               : a.audio + ((size_t) s * a.stride + (size_t) fc) * C;
-			// history rows are [frame][2] with a zero right channel for mono engines: p[0] is the sample either way
-			v[r] = C == 2 ? *reinterpret_cast<const v2f*> (p) : v2f{p[0], 0.f};
+		for (int k = 0; k < 12; ++k) {
+			taps.p[k] = v2f{pmq[2 * k], pmq[2 * k + 1]};
+			taps.m[k] = v2f{pmq[24 + 2 * k], pmq[25 + 2 * k]};
+			taps.q[k] = v2f{pmq[48 + 2 * k], pmq[49 + 2 * k]};
+			asm volatile ("" : "+v"(taps.p[k]), "+v"(taps.m[k]), "+v"(taps.q[k]));   // keep them in vector registers
+		}
+	}
+
+	// ---- waves 1..NW-1 fetch: element e = 64 k + lane of a chunk is (row e / F, frame e % F); wave w owns the
+	//      wave-wide loads k = w - 1 and w + 6.  Only the F new frames of a row are read per chunk (HBM and
+	//      the texture path see each frame once; the first version re-read the 48-frame window every chunk
+	//      and spent as long issuing loads as interpolating).  Every load is unconditional (address clamped,
+	//      the mask applied when the value is stored): a load inside a divergent branch is waited for at the
+	//      end of its branch.
+	const float* rowp[LPW];
+	int slot[LPW], ldso[LPW];
+	bool live[LPW];
+#pragma unroll
+	for (int i = 0; i < LPW; ++i) {
+		const int e = 64 * (wid - 1 + (NW - 1) * i) + lane;
+		const int row = (e / F) & (NS - 1);
+		slot[i] = e % F;
+		ldso[i] = row * IN_STRIDE + slot[i];
+		live[i] = s0 + (uint32_t) row < a.n_streams;
+		rowp[i] = a.audio + (size_t) (live[i] ? s0 + (uint32_t) row : s0) * a.stride * C;
+	}
+	auto fetch = [&] (int64_t j, v2f (&v)[LPW]) {
+#pragma unroll
+		for (int i = 0; i < LPW; ++i) {
+			if (wid - 1 + (NW - 1) * i >= NLOAD) break;                 // wave-uniform
+			const int64_t f = j * F + slot[i];
+			const float* const q = rowp[i] + (size_t) (f < (int64_t) a.n_frames ? f : 0) * C;
+			v[i] = C == 2 ? *reinterpret_cast<const v2f*> (q) : v2f{q[0], 0.f};
 		}
 	};
-	auto put = [&] (int64_t j, const v2f (&v)[ROWS]) {
-		v2f* const dst = in_buf + (j & 1) * NS * IN_STRIDE;
-		const int64_t f = j * F - 48 + lane;
-		const bool ok = f >= -MTR_FIR_HALO && f < (int64_t) a.n_frames;
+	auto put = [&] (int64_t j, int ring_chunk, const v2f (&v)[LPW]) {
 #pragma unroll
-		for (int r = 0; r < ROWS; ++r) {
-			const bool live = s0 + (uint32_t) (row0 + r) < a.n_streams;
-			dst[(row0 + r) * IN_STRIDE + lane] = (ok && live) ? v[r] : v2f{0.f, 0.f};
+		for (int i = 0; i < LPW; ++i) {
+			if (wid - 1 + (NW - 1) * i >= NLOAD) break;
+			const bool ok = live[i] && j * F + slot[i] < (int64_t) a.n_frames;
+			v2f* const dst = in_buf + ldso[i] + ring_chunk * F;
+			const v2f x = ok ? v[i] : v2f{0.f, 0.f};
+			dst[0] = x;
+			dst[RING] = x;
 		}
 	};
 
@@ -159,28 +238,57 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		z2 = v2f{z2.x > 20 ? 20 : (z2.x < 0 ? 0 : z2.x), z2.y > 20 ? 20 : (z2.y < 0 ? 0 : z2.y)};
 	}
 
-	if (fir) {                                                           // prologue: chunk 0 into buffer 0
-		v2f v[ROWS];
+	if (fir) {
+		// prologue: the 48 frames before the call (47 of history, frame -48 is never multiplied by a non-zero
+		// tap) into ring chunks 2..5, chunk 0 into ring chunk 0
+		for (int e = (wid - 1) * 64 + lane; e < NS * 48; e += (NW - 1) * 64) {
+			const int row = e / 48, i = e % 48;                          // frame i - 48
+			v2f x = {0.f, 0.f};
+			if (s0 + (uint32_t) row < a.n_streams && i >= 1) {
+				// history rows are [frame][2] with a zero right channel for mono engines
+				const float* const h = a.hist + ((size_t) (s0 + (uint32_t) row) * MTR_FIR_HALO + (size_t) (i - 1)) * 2;
+				x = C == 2 ? v2f{h[0], h[1]} : v2f{h[0], 0.f};
+			}
+			v2f* const dst = in_buf + row * IN_STRIDE + 2 * F + i;
+			dst[0] = x;
+			dst[RING] = x;
+		}
+		v2f v[LPW];
 		fetch (0, v);
-		put (0, v);
+		put (0, 0, v);
 	}
 	__syncthreads ();
 
-	// iteration t: rows of chunk t+1 are fetched, chunk t is interpolated, chunk t-1 goes through the recurrence
+	// iteration t: the new frames of chunk t+1 are fetched, chunk t is interpolated, chunk t-1 goes through
+	// the recurrence.  rd = ring chunk where the window of chunk t starts (frame 12 t - 48), wr = where chunk
+	// t+1 goes.
+#ifdef MTR_TPB_PROF
+	unsigned long long pr[4] = { 0, 0, 0, 0 };
+#endif
+	int rd = 2, wr = 1;
 	for (int64_t t = 0; t <= n_chunks; ++t) {
+		PROF_NOW (c0_);
 		if (fir) {
-			v2f nxt[ROWS];
+			v2f nxt[LPW];
 			const bool more = t + 1 < n_chunks;
 			if (more) fetch (t + 1, nxt);
-			if (t < n_chunks) {
-				const v2f* const xs = in_buf + (t & 1) * NS * IN_STRIDE + lane * IN_STRIDE + R * wid;
-				v2f o[4 * R];
-				interpolate (xs, pmq, o);
-				v2f* const dst = ov_buf + (t & 1) * NS * OV_STRIDE + lane * OV_STRIDE + 4 * R * wid;
+			PROF_NOW (cf_);
+			PROF_ADD (2, cf_ - c0_);
+			if (t < n_chunks && item0 >= 0) {
+				for (int g = item0; g < NGRP; g += n_interp) {
+					const v2f* const xs = in_buf + lane * IN_STRIDE + rd * F + R * g;
+					v2f o[4 * R];
+					interpolate (xs, taps, o);
+					v2f* const dst = ov_buf + (t & 1) * NS * OV_STRIDE + lane * OV_STRIDE + 4 * R * g;
 #pragma unroll
-				for (int i = 0; i < 4 * R; ++i) dst[i] = o[i];
+					for (int i = 0; i < 4 * R; ++i) dst[i] = o[i];
+				}
 			}
-			if (more) put (t + 1, nxt);
+			PROF_NOW (c1_);
+			PROF_ADD (0, c1_ - c0_);
+			if (more) put (t + 1, wr, nxt);
+			PROF_NOW (c2_);
+			PROF_ADD (1, c2_ - c1_);
 		} else if (t > 0) {
 			const int64_t c0 = (t - 1) * F;
 			const int nf = (int) min ((int64_t) F, (int64_t) a.n_frames - c0);
@@ -206,8 +314,20 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 				if (f + 1 < F) { v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2]; v[3] = nv[3]; }
 			}
 		}
+		PROF_NOW (c3_);
 		__syncthreads ();
+		PROF_NOW (c4_);
+		if (!fir) { PROF_ADD (0, c3_ - c0_); PROF_ADD (2, c4_ - c3_); }
+		PROF_ADD (3, c4_ - c0_);
+		rd = rd == 5 ? 0 : rd + 1;
+		wr = wr == 5 ? 0 : wr + 1;
 	}
+#ifdef MTR_TPB_PROF
+	if (blockIdx.x == 0 && lane == 0) {
+		for (int i = 0; i < 4; ++i) g_tpb_prof[wid][i] = pr[i];
+		g_tpb_prof[8 + wid][0] = simd_of[wid]; g_tpb_prof[8 + wid][1] = item0; g_tpb_prof[8 + wid][2] = n_interp;
+	}
+#endif
 
 	if (!fir && sl < a.n_streams) {
 		st->tpb_z1[0] = z1.x + 1e-20f; st->tpb_z1[1] = z1.y + 1e-20f;     // truepeakdsp.cc:86-87
@@ -234,13 +354,17 @@ __global__ void k_history_mono (const float* audio, uint64_t stride, uint64_t n_
 
 int mtr_launch_tpb (const mtr_tpb_args& a, void* stream)
 {
-	const size_t lds = (size_t) 2 * NS * (IN_STRIDE + OV_STRIDE) * sizeof (v2f);      // 130 KiB: one workgroup per CU
+	const size_t lds = (size_t) NS * (IN_STRIDE + 2 * OV_STRIDE) * sizeof (v2f);      // 110 KiB: one workgroup per CU
 	static bool raised = false;
 	if (!raised) {
-		(void) hipFuncSetAttribute ((const void*) k_tpb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void) hipFuncSetAttribute ((const void*) k_tpb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		(void) hipFuncSetAttribute ((const void*) k_tpb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 		raised = true;
 	}
-	hipLaunchKernelGGL (k_tpb, dim3 ((a.n_streams + NS - 1) / NS), dim3 (NTHREADS), lds, (hipStream_t) stream, a);
+	if (a.n_channels == 2)
+		hipLaunchKernelGGL (k_tpb<2>, dim3 ((a.n_streams + NS - 1) / NS), dim3 (NTHREADS), lds, (hipStream_t) stream, a);
+	else
+		hipLaunchKernelGGL (k_tpb<1>, dim3 ((a.n_streams + NS - 1) / NS), dim3 (NTHREADS), lds, (hipStream_t) stream, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
