@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "mtr_internal.h"
+#include "mtr_mfma_fir.h"
 
 static thread_local std::string g_err;
 
@@ -47,7 +48,7 @@ struct Plan {
 	uint64_t n_frames = 0;
 	uint32_t frcnt_in = 0;      // frames left in the open fragment when the call starts
 	uint32_t frcnt_out = 0;
-	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0, buf_slots = 0, kw_slots = 0;
+	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0, buf_slots = 0, kw_slots = 0, mfma_words = 0;
 	bool     valid = false;
 };
 
@@ -78,6 +79,7 @@ struct mtr_engine {
 	DevBuf<mtr_sigdist_state>  sdh;
 	DevBuf<float>    fir_g;         // [3][48] taps in device memory
 	DevBuf<float>    fir_pmq;       // [3][24] the same in mirror-symmetric form (ballistics kernel)
+	DevBuf<uint16_t> mfma_a;        // layout 5: A fragments of the MFMA interpolator (mtr_mfma_fir.h)
 	DevBuf<uint32_t> prune_cnt;     // [2] interpolator tile passes considered / skipped
 	uint64_t         prune_tot[2] = { 0, 0 };
 	float            tpb_w[4];      // w1 w2 w3 g of TruePeakdsp::init
@@ -164,6 +166,13 @@ static int upload_consts (mtr_engine* e)
 		if (e->fir_pmq.reserve (72)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_pmq");
 		HIPCHK (hipMemcpy (e->fir_pmq.p, pmq, sizeof (pmq), hipMemcpyHostToDevice));
 	}
+	{
+		// and as A fragments of the matrix-pipe interpolator (layout 5)
+		std::vector<uint16_t> af (MTR_MFMA_A_HALVES);
+		mtr_mfma_build_a (&g[0][0], af.data ());
+		if (e->mfma_a.reserve (af.size ())) return fail (MTR_ERR_NOMEM, "hipMalloc mfma_a");
+		HIPCHK (hipMemcpy (e->mfma_a.p, af.data (), af.size () * sizeof (uint16_t), hipMemcpyHostToDevice));
+	}
 	// TruePeakdsp::init, jmeters/truepeakdsp.cc:154-157 — float / float / double, stored as float
 	const float fs = e->cfg.sample_rate;
 	e->tpb_w[0] = 4000.0f / fs / 4.0;
@@ -246,11 +255,12 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	const bool kw_only = (cfg->meters & MTR_METER_EBU) && !(cfg->meters & MTR_METER_TRUEPEAK);
 	e->layout = cfg->tune_layout ? (int) cfg->tune_layout : (cfg->tune_run == 13 ? 1 : (kw_only ? 4 : 3));
 	e->run = cfg->tune_run ? (int) cfg->tune_run : 39;
-	if (e->layout > 4) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..4"); }
+	if (e->layout > 5) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..5"); }
+	if (e->layout == 5 && (!(cfg->meters & MTR_METER_TRUEPEAK) || e->run == 13)) { delete e; return fail (MTR_ERR_ARG, "layout 5 is the MFMA true-peak kernel: needs TRUEPEAK and tune_run 19 or 39"); }
 	if (e->layout == 4 && !kw_only) { delete e; return fail (MTR_ERR_ARG, "layout 4 is the EBU-only kernel"); }
 	if ((e->layout == 2 || e->layout == 3) && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layouts 2 and 3 need tune_run 39"); }
 	if (e->layout == 4 && e->run == 13) { delete e; return fail (MTR_ERR_ARG, "layout 4 needs tune_run 19 or 39"); }
-	if (e->layout == 1 && e->run == 19) { delete e; return fail (MTR_ERR_ARG, "tune_run 19 is layout 4 only"); }
+	if (e->layout == 1 && e->run == 19) { delete e; return fail (MTR_ERR_ARG, "tune_run 19 is layouts 4 and 5 only"); }
 	e->fragm = (uint32_t) ((int) cfg->sample_rate / 20);     // ebu_r128_proc.cc:170
 	e->frcnt = e->fragm;
 	mtr_setup_kweight (cfg->sample_rate, e->kw);
@@ -301,7 +311,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->scan_m.release (); e->bin_power.release (); e->tile_power.release (); e->frag_power.release ();
 	e->stage.release (); e->tile_start.release (); e->seg_tile.release (); e->frag_tile.release ();
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
-	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release ();
+	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release (); e->mfma_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
 	delete e;
 }
@@ -479,6 +489,7 @@ static int build_plan (mtr_engine* e, uint64_t N)
 	// + look-ahead frames of the FIR register tile + 4 slots for the carried K-filter state (layout 3)
 	pl.buf_slots = (maxlen + 48 + 13 + 4 + 127) / 128 * 128;
 	pl.kw_slots = (maxlen + 1 + 127) / 128 * 128;               // k_kw: the tile + one frame of alignment slack
+	pl.mfma_words = (MTR_FIR_HALO + maxlen + 12 + 3) / 4 * 4;   // k_kwtp: halo + tile + the 9 words a column reads past its window
 	pl.valid = true;
 	return MTR_OK;
 }
@@ -525,12 +536,14 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.c3 = e->kw[5]; fa.c4 = e->kw[6];
 		fa.gain_l = 1.0f; fa.gain_r = 1.0f;                  // _chan_gain[0..1], ebu_r128_proc.cc:29
 		fa.n_frames = n_frames;
-		fa.buf_slots = e->layout == 4 ? pl.kw_slots : pl.buf_slots;
+		fa.buf_slots = e->layout >= 4 ? pl.kw_slots : pl.buf_slots;
+		fa.mfma_a = e->mfma_a.p; fa.mfma_words = pl.mfma_words;
 		fa.fir_form = e->cfg.tune_fir;
 		fa.rotate = e->layout == 3;
 		fa.prune = e->cfg.tune_prune ? 1 : 0;
 		fa.prune_stats = e->prune_cnt.p;
-		const int lrc = e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
+		const int lrc = e->layout == 5 ? mtr_launch_kwtp (e->run, ebu, fa, S * pl.n_segs, st)
+		              : e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
 		              : e->layout >= 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
 		                               : mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st);
 		if (lrc) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());

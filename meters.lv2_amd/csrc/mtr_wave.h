@@ -48,6 +48,18 @@ __device__ __forceinline__ float sum63 (float v)
 	return __int_as_float (__builtin_amdgcn_readlane (__float_as_int (v), 63));
 }
 
+// max over the wave of NON-NEGATIVE values (lanes without a source read 0), returned wave-uniform
+__device__ __forceinline__ float max63 (float v)
+{
+	v = fmaxf (v, dpp0<0x111, 0xF> (v));
+	v = fmaxf (v, dpp0<0x112, 0xF> (v));
+	v = fmaxf (v, dpp0<0x114, 0xF> (v));
+	v = fmaxf (v, dpp0<0x118, 0xF> (v));
+	v = fmaxf (v, dpp0<0x142, 0xA> (v));
+	v = fmaxf (v, dpp0<0x143, 0xC> (v));
+	return __int_as_float (__builtin_amdgcn_readlane (__float_as_int (v), 63));
+}
+
 // One application of a K-weighting transition-matrix power (block lower triangular: the shelving
 // stage does not see the integrators): z += M w.
 #define MTRW_APPLY(M, w1, w2, w3, w4)                                                     \
