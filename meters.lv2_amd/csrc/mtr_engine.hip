@@ -489,7 +489,8 @@ static int build_plan (mtr_engine* e, uint64_t N)
 	// + look-ahead frames of the FIR register tile + 4 slots for the carried K-filter state (layout 3)
 	pl.buf_slots = (maxlen + 48 + 13 + 4 + 127) / 128 * 128;
 	pl.kw_slots = (maxlen + 1 + 127) / 128 * 128;               // k_kw: the tile + one frame of alignment slack
-	pl.mfma_words = (MTR_FIR_HALO + maxlen + 12 + 3) / 4 * 4;   // k_kwtp: halo + tile + the 9 words a column reads past its window
+	// k_kwtp: halo + the 64 lane runs (written in full, zeros past the tile) + the 9 words a column reads past its window
+	pl.mfma_words = (MTR_FIR_HALO + std::max (maxlen, LT) + 12 + 3) / 4 * 4;
 	pl.valid = true;
 	return MTR_OK;
 }

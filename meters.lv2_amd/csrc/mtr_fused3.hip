@@ -23,6 +23,16 @@
 #include "mtr_mfma_fir.h"
 #include "mtr_wave.h"
 
+// -DMTR_F3_PROF: cycles per phase, summed over the tiles of workgroup 0 (read back with mtr_debug_f3_prof)
+#ifdef MTR_F3_PROF
+__device__ unsigned long long g_f3_prof[8];
+#define PROF_NOW(v) unsigned long long v; asm volatile ("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define PROF_ADD(i, d) pr[i] += (d)
+#else
+#define PROF_NOW(v)
+#define PROF_ADD(i, d)
+#endif
+
 namespace {
 
 __device__ __forceinline__ v2f scrub (v2f v) { return v2f{isfinite (v.x) ? v.x : 0.f, isfinite (v.y) ? v.y : 0.f}; }
@@ -42,7 +52,11 @@ __device__ __forceinline__ v2f scrub (v2f v) { return v2f{isfinite (v.x) ? v.x :
 
 constexpr int HALO = MTR_FIR_HALO;       // 47
 
-template <int K, bool EBU>
+// INPLACE: the word arrays take the place of the f32 tile once it sits in registers, so a wave needs ONE
+// region of LDS (20 KB at K = 39) and two waves fit a SIMD — at the price of fetching the next tile only
+// after this one's products (the other wave of the SIMD covers that wait).  The halo words cross the
+// fetch in registers.
+template <int K, bool EBU, bool INPLACE>
 __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 {
 	static_assert ((K & 1) == 1, "odd lane stride: conflict-free LDS accesses");
@@ -52,7 +66,7 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 	const int wn = (int) a.mfma_words;                                   // words per channel, a multiple of 4
 	uint32_t* const WL = reinterpret_cast<uint32_t*> (smem);
 	uint32_t* const WR = WL + wn;
-	v2f* const buf = reinterpret_cast<v2f*> (WR + wn);
+	v2f* const buf = INPLACE ? reinterpret_cast<v2f*> (smem) : reinterpret_cast<v2f*> (WR + wn);
 	const int lane = threadIdx.x;
 
 	const uint32_t unit = blockIdx.x;
@@ -61,7 +75,10 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 	const v2f* const src = reinterpret_cast<const v2f*> (a.audio) + (size_t) s * a.stride;
 	mtr_stream_state* const st = a.state + s;
 	const bool src_even = ((((size_t) s * a.stride) & 1) == 0) && ((reinterpret_cast<size_t> (a.audio) & 15) == 0);
-	const float a0 = a.a0, a1 = a.a1, a2 = a.a2, b1 = a.b1, b2 = a.b2, c3 = a.c3, c4 = a.c4;
+	// The K-filter coefficients live in vector registers here: pass 1 wants 4 K scalars at once, the scalar file
+	// overflows, and spilled scalars cost a v_readlane per use — eight per frame in pass 2 when they were these.
+	v2f a0 = a.a0, a1 = a.a1, a2 = a.a2, b1 = a.b1, b2 = a.b2, c3 = a.c3, c4 = a.c4;
+	asm volatile ("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b1), "+v"(b2), "+v"(c3), "+v"(c4));
 
 	const uint32_t jt0 = a.seg_tile[q], jt1 = a.seg_tile[q + 1];
 	const int64_t seg_start = a.tile_start[jt0];
@@ -115,44 +132,63 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 	asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
 	// halo of the first tile: the 47 frames before the call (segment 0) — later segments get theirs from the
 	// warm-up tiles, which are converted like any other
+	uint32_t halo_l = 0u, halo_r = 0u;                                   // INPLACE: lanes 0..46 carry the halo words
 	if (lane < HALO) {
-		uint32_t wl = 0u, wr = 0u;
 		if (q == 0) {
 			const float* const h = a.hist + ((size_t) s * HALO + (size_t) lane) * 2;
-			wl = mfir::split_word (h[0]);
-			wr = mfir::split_word (h[1]);
+			halo_l = mfir::split_word (h[0]);
+			halo_r = mfir::split_word (h[1]);
 		}
-		WL[lane] = wl;
-		WR[lane] = wr;
+		WL[lane] = halo_l;
+		WR[lane] = halo_r;
 	}
+	asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+#ifdef MTR_F3_PROF
+	unsigned long long pr[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
 	stage (-nwarm);
 	for (int jj = -nwarm; jj < ntile; ++jj) {
 		int64_t t0; int len;
 		tile_of (jj, t0, len);
+		PROF_NOW (c0_);
 		const int run0 = lane * K;
 		const int rl = min (max (len - run0, 0), K);
 		const v2f* const xr = buf + (int) (t0 & 1) + run0;
 
 		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed
 		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+		PROF_NOW (c1_); PROF_ADD (0, c1_ - c0_);
 
 		v2f x[K];
 #pragma unroll
 		for (int n = 0; n < K; ++n) x[n] = xr[n];
 		asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");    // every read has returned: the buffer is free
-		if (jj + 1 < ntile) stage (jj + 1);
+		if (!INPLACE && jj + 1 < ntile) stage (jj + 1);
+		// slots past the tile hold stale data: zero them once, here, so that nothing below needs a per-frame test
+		// (a per-frame `if (n < rl)` is a lane-mask update and a branch per frame)
+#pragma unroll
+		for (int n = 0; n < K; ++n) x[n] = n < rl ? x[n] : v2f{0.f, 0.f};
+		PROF_NOW (c2_); PROF_ADD (1, c2_ - c1_);
 
 		// the run as {hi, lo} words behind the halo
 		{
+			if (INPLACE) {
+				// the tile was lying over both arrays: put the halo back, and zeros into the pad behind the left array
+				if (lane < HALO) { WL[lane] = halo_l; WR[lane] = halo_r; }
+				if (lane < 12) WL[HALO + 64 * K + lane] = 0u;
+			}
 			uint32_t* const wl = WL + HALO + run0;
 			uint32_t* const wr = WR + HALO + run0;
 #pragma unroll
 			for (int n = 0; n < K; ++n) {
-				if (n < rl) { uint32_t l_, r_; mfir::split_words (x[n].x, x[n].y, l_, r_); wl[n] = l_; wr[n] = r_; }
+				uint32_t l_, r_;
+				mfir::split_words (x[n].x, x[n].y, l_, r_);
+				wl[n] = l_; wr[n] = r_;              // all 64 K positions: past the tile they are zeros
 			}
 		}
 
+		PROF_NOW (c3_); PROF_ADD (2, c3_ - c2_);
 		if (EBU) {
 			v2f z1 = e1, z2 = e2, z3 = e3, z4 = e4;
 #pragma unroll
@@ -167,16 +203,24 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 				z3 += M[8] * k1 + M[9] * k2 + M[10] * k3 + M[11] * k4;
 				z4 += M[12] * k1 + M[13] * k2 + M[14] * k3 + M[15] * k4;
 			}
+			PROF_NOW (p1_); PROF_ADD (5, p1_ - c3_);
 			mtrw::scan (z1, z2, z3, z4, CM, rm);
+			PROF_NOW (p2_); PROF_ADD (0, p2_ - p1_);
 			if (jj < 0) {
 				k1 = mtrw::pick (z1, 63); k2 = mtrw::pick (z2, 63); k3 = mtrw::pick (z3, 63); k4 = mtrw::pick (z4, 63);
 			} else {
 				z1 = mtrw::from_left (z1); z2 = mtrw::from_left (z2); z3 = mtrw::from_left (z3); z4 = mtrw::from_left (z4);
 				if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
+				// Only one lane has a partial run (the tile's last active one): the set of lanes that take step n is
+				// "up to and including it" while n < its run length and "all before it" afterwards — two
+				// loop-invariant lane masks and a scalar test per step, not a vector compare per step.
+				const int last_l = (len - 1) / K, rl_last = len - last_l * K;
+				const bool upto = lane <= last_l, before = lane < last_l;
 				v2f sj = 0;
 #pragma unroll
 				for (int n = 0; n < K; ++n) {
-					if (n < rl) { v2f y; KW_STEP (x[n], y); sj += y * y; }
+					if (n < rl_last) { if (upto) { v2f y; KW_STEP (x[n], y); sj += y * y; } }
+					else             { if (before) { v2f y; KW_STEP (x[n], y); sj += y * y; } }
 				}
 				const float sl = mtrw::sum63 (sj.x), sr = mtrw::sum63 (sj.y);
 				if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = a.gain_l * sl + a.gain_r * sr;
@@ -186,6 +230,7 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 			k1 = scrub (k1); k2 = scrub (k2); k3 = scrub (k3); k4 = scrub (k4);
 		}
 
+		PROF_NOW (c4_); PROF_ADD (3, c4_ - c3_);
 		// the interpolator: 256 output frames x 4 phases per MFMA tile and channel
 		if (jj >= 0) {
 			__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
@@ -194,7 +239,8 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 			mfir::BFrag bl, br;
 			mfir::fetch_b (bl, WL, 0, lane);
 			mfir::fetch_b (br, WR, 0, lane);
-			for (int b0 = 0; b0 < len; b0 += 256) {
+			int b0 = 0;
+			for (; b0 + 256 <= len; b0 += 256) {
 				// the next block's operands are fetched under this block's products (past the last block the
 				// read is harmless: finite words inside the allocation)
 				mfir::BFrag nl, nr;
@@ -202,31 +248,47 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 				mfir::fetch_b (nr, WR, b0 + 256, lane);
 				mfir::f16x yl, yr;
 				mfir::tile2 (A, bl, br, yl, yr);
-				if (b0 + 256 <= len) {
 #pragma unroll
-					for (int r = 0; r < 16; r += 2) {
-						pk_l = fmaxf (fmaxf (pk_l, fabsf (yl[r])), fabsf (yl[r + 1]));
-						pk_r = fmaxf (fmaxf (pk_r, fabsf (yr[r])), fabsf (yr[r + 1]));
-					}
-				} else {
-					// the tile's last block: frames past its end belong to the next tile (or do not exist yet)
-#pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						if (b0 + fo + (r & 3) < len) { pk_l = fmaxf (pk_l, fabsf (yl[r])); pk_r = fmaxf (pk_r, fabsf (yr[r])); }
-					}
+				for (int r = 0; r < 16; r += 2) {
+					pk_l = fmaxf (fmaxf (pk_l, fabsf (yl[r])), fabsf (yl[r + 1]));
+					pk_r = fmaxf (fmaxf (pk_r, fabsf (yr[r])), fabsf (yr[r + 1]));
 				}
 				bl = nl; br = nr;
 			}
+			if (b0 < len) {
+				// the tile's last block: frames past its end belong to the next tile (or do not exist yet).
+				// Register r holds output frame b0 + fo + (r & 3): four lane masks.
+				mfir::f16x yl, yr;
+				mfir::tile2 (A, bl, br, yl, yr);
+				const int lim = len - b0 - fo;
+				float ml = 0.f, mr = 0.f;
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					const bool ok = (r & 3) < lim;
+					ml = fmaxf (ml, ok ? fabsf (yl[r]) : 0.f);
+					mr = fmaxf (mr, ok ? fabsf (yr[r]) : 0.f);
+				}
+				pk_l = fmaxf (pk_l, ml);
+				pk_r = fmaxf (pk_r, mr);
+			}
 		}
 
+		PROF_NOW (c5_); PROF_ADD (4, c5_ - c4_);
 		// the next tile's halo: the last 47 frames before t0 + len sit at positions len .. len + 46
 		{
-			uint32_t hl = 0u, hr = 0u;
-			if (lane < HALO) { hl = WL[len + lane]; hr = WR[len + lane]; }
+			if (lane < HALO) { halo_l = WL[len + lane]; halo_r = WR[len + lane]; }
 			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
-			if (lane < HALO) { WL[lane] = hl; WR[lane] = hr; }
+			if (INPLACE) {
+				if (jj + 1 < ntile) stage (jj + 1);                // over the words: they are spent
+			} else if (lane < HALO) {
+				WL[lane] = halo_l; WR[lane] = halo_r;
+			}
 		}
+		PROF_NOW (c6_); PROF_ADD (5, c6_ - c5_); PROF_ADD (6, c6_ - c0_); PROF_ADD (7, 1);
 	}
+#ifdef MTR_F3_PROF
+	if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 8; ++i) g_f3_prof[i] = pr[i];
+#endif
 	if (EBU && q == a.n_segs - 1 && lane == 0) {
 		st->kz[0] = k1.x; st->kz[1] = k1.y; st->kz[2] = k2.x; st->kz[3] = k2.y;
 		st->kz[4] = k3.x; st->kz[5] = k3.y; st->kz[6] = k4.x; st->kz[7] = k4.y;
@@ -241,11 +303,18 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 }
 
 template <int K>
-int launch_kwtp (bool ebu, const mtr_fused_args& a, uint32_t n_units, hipStream_t st)
+int launch_kwtp (bool ebu, bool inplace, const mtr_fused_args& a, uint32_t n_units, hipStream_t st)
 {
-	const size_t lds = (size_t) a.buf_slots * sizeof (v2f) + (size_t) 2 * a.mfma_words * sizeof (uint32_t);
-	if (ebu) hipLaunchKernelGGL ((k_kwtp<K, true>), dim3 (n_units), dim3 (64), lds, st, a);
-	else     hipLaunchKernelGGL ((k_kwtp<K, false>), dim3 (n_units), dim3 (64), lds, st, a);
+	const size_t words = (size_t) 2 * a.mfma_words * sizeof (uint32_t), tile = (size_t) a.buf_slots * sizeof (v2f);
+	if (inplace) {
+		const size_t lds = words > tile ? words : tile;
+		if (ebu) hipLaunchKernelGGL ((k_kwtp<K, true, true>), dim3 (n_units), dim3 (64), lds, st, a);
+		else     hipLaunchKernelGGL ((k_kwtp<K, false, true>), dim3 (n_units), dim3 (64), lds, st, a);
+	} else {
+		const size_t lds = words + tile;
+		if (ebu) hipLaunchKernelGGL ((k_kwtp<K, true, false>), dim3 (n_units), dim3 (64), lds, st, a);
+		else     hipLaunchKernelGGL ((k_kwtp<K, false, false>), dim3 (n_units), dim3 (64), lds, st, a);
+	}
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
@@ -253,9 +322,17 @@ int launch_kwtp (bool ebu, const mtr_fused_args& a, uint32_t n_units, hipStream_
 
 int mtr_launch_kwtp (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream)
 {
+	const bool inplace = a.fir_form != 3;                                // tune_fir = 3: separate tile buffer (first form, kept for comparison)
 	switch (run) {
-	case 39: return launch_kwtp<39> (ebu, a, n_units, (hipStream_t) stream);
-	case 19: return launch_kwtp<19> (ebu, a, n_units, (hipStream_t) stream);
+	case 39: return launch_kwtp<39> (ebu, inplace, a, n_units, (hipStream_t) stream);
+	case 19: return launch_kwtp<19> (ebu, inplace, a, n_units, (hipStream_t) stream);
 	default: return -2;
 	}
 }
+
+#ifdef MTR_F3_PROF
+extern "C" int mtr_debug_f3_prof (unsigned long long* out)
+{
+	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_f3_prof), 8 * sizeof (unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
