@@ -58,12 +58,16 @@ typedef struct {
 	float    sample_rate;    /* Hz; reference: instantiate()'s `rate` (src/meters.cc:194) */
 	int32_t  device;         /* HIP device ordinal */
 	uint32_t max_frames;     /* largest n_frames a process call will carry (scratch sizing); 0 = grow on demand */
-	uint32_t tune_run;       /* frames per lane run of the fused kernel: 0 = auto, else 13, 39 (19: layout 4 only) */
+	uint32_t tune_run;       /* frames per lane run of the fused kernel: 0 = auto, else 13, 39 (19: layouts 4 and 5 only) */
 	uint32_t tune_segments;  /* time segments per stream per call: 0 = auto */
 	uint32_t tune_layout;    /* 0 = auto, 1 = one wave per stream segment, 2 = wave-specialised workgroups (run 39),
 	                          * 3 = as 2 with the loader / K-filter role rotating over the four waves (auto for EBU + TP),
-	                          * 4 = the K-weighting-only kernel (EBU without TRUEPEAK; auto for that mask) */
-	uint32_t tune_fir;       /* interpolator form: 0 = auto (mirror-symmetric), 1 = dense 3 x 48 taps */
+	                          * 4 = the K-weighting-only kernel (EBU without TRUEPEAK; auto for that mask),
+	                          * 5 = OPT-IN: layout 4 plus the interpolator on the matrix pipe (f16-split samples, f16 taps,
+	                          *     f32 accumulation; needs TRUEPEAK, run 19 or 39).  True peaks within 0.0056 dB of the
+	                          *     f32 interpolator of layouts 1-3 — inside the +-0.01 dB tolerance, not bit-identical */
+	uint32_t tune_fir;       /* interpolator form: 0 = auto (mirror-symmetric), 1 = dense 3 x 48 taps;
+	                          * layout 5 only: 3 = separate f32 tile buffer (first form, one wave per SIMD) */
 	uint32_t tune_prune;     /* 1 = exact true-peak pruning (branch and bound on L1 * max|x|): identical result,
 	                          * data-dependent speed; off by default so the default timing is the dense one */
 } mtr_config;
