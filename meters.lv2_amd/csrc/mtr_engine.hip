@@ -254,14 +254,13 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	// layout 4 = k_kw, the K-weighting-only kernel (mtr_kw.hip): the default when no true peak is asked for
 	const bool kw_only = (cfg->meters & MTR_METER_EBU) && !(cfg->meters & MTR_METER_TRUEPEAK);
 	e->layout = cfg->tune_layout ? (int) cfg->tune_layout : (cfg->tune_run == 13 ? 1 : (kw_only ? 4 : 3));
-	e->run = cfg->tune_run ? (int) cfg->tune_run : (e->layout == 6 ? 19 : 39);
-	if (e->layout > 6) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..6"); }
-	if (e->layout == 6 && (!(cfg->meters & MTR_METER_TRUEPEAK) || e->run != 19)) { delete e; return fail (MTR_ERR_ARG, "layout 6 is the two-wave MFMA true-peak kernel: needs TRUEPEAK and tune_run 0 or 19"); }
+	e->run = cfg->tune_run ? (int) cfg->tune_run : 39;
+	if (e->layout > 5) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..5"); }
 	if (e->layout == 5 && (!(cfg->meters & MTR_METER_TRUEPEAK) || e->run == 13)) { delete e; return fail (MTR_ERR_ARG, "layout 5 is the MFMA true-peak kernel: needs TRUEPEAK and tune_run 19 or 39"); }
 	if (e->layout == 4 && !kw_only) { delete e; return fail (MTR_ERR_ARG, "layout 4 is the EBU-only kernel"); }
 	if ((e->layout == 2 || e->layout == 3) && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layouts 2 and 3 need tune_run 39"); }
 	if (e->layout == 4 && e->run == 13) { delete e; return fail (MTR_ERR_ARG, "layout 4 needs tune_run 19 or 39"); }
-	if (e->layout == 1 && e->run == 19) { delete e; return fail (MTR_ERR_ARG, "tune_run 19 is layouts 4, 5 and 6 only"); }
+	if (e->layout == 1 && e->run == 19) { delete e; return fail (MTR_ERR_ARG, "tune_run 19 is layouts 4 and 5 only"); }
 	e->fragm = (uint32_t) ((int) cfg->sample_rate / 20);     // ebu_r128_proc.cc:170
 	e->frcnt = e->fragm;
 	mtr_setup_kweight (cfg->sample_rate, e->kw);
@@ -544,8 +543,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.rotate = e->layout == 3;
 		fa.prune = e->cfg.tune_prune ? 1 : 0;
 		fa.prune_stats = e->prune_cnt.p;
-		const int lrc = e->layout == 6 ? mtr_launch_kwtp2 (e->run, ebu, fa, S * pl.n_segs, st)
-		              : e->layout == 5 ? mtr_launch_kwtp (e->run, ebu, fa, S * pl.n_segs, st)
+		const int lrc = e->layout == 5 ? mtr_launch_kwtp (e->run, ebu, fa, S * pl.n_segs, st)
 		              : e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
 		              : e->layout >= 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
 		                               : mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st);

@@ -125,7 +125,6 @@ int  mtr_launch_fused (int run, bool ebu, bool tp, const mtr_fused_args& a, uint
 int  mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kw (int run, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kwtp (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
-int  mtr_launch_kwtp2 (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_fused2_upload_taps (const float* g144);
 int  mtr_fused_upload_taps (const float* g144);    /* [3][48] full 48-tap kernels of phases 1..3 */
 int  mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,

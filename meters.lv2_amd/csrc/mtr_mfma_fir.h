@@ -147,24 +147,5 @@ __device__ __forceinline__ void tile2 (const AFrag& A, const BFrag& L, const BFr
 	}
 }
 
-// The same product with the operands read as they are used, one step ahead (16 registers instead of 56).
-__device__ __forceinline__ void tile2_stream (const AFrag& A, const uint32_t* WL, const uint32_t* WR, int base, int lane, f16x& yl, f16x& yr)
-{
-	const int o = base + 8 * (lane & 31) + 4 * (lane >> 5);
-	const uint4* const pl = reinterpret_cast<const uint4*> (WL + o);
-	const uint4* const pr = reinterpret_cast<const uint4*> (WR + o);
-	const f16x z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-	yl = z; yr = z;
-	uint4 l = pl[0], r = pr[0];
-#pragma unroll
-	for (int j = 0; j < MTR_MFMA_STEPS; ++j) {
-		uint4 nl = l, nr = r;
-		if (j + 1 < MTR_MFMA_STEPS) { nl = pl[2 * (j + 1)]; nr = pr[2 * (j + 1)]; }
-		yl = __builtin_amdgcn_mfma_f32_32x32x16_f16 (A.a[j], __builtin_bit_cast (h8, l), yl, 0, 0, 0);
-		yr = __builtin_amdgcn_mfma_f32_32x32x16_f16 (A.a[j], __builtin_bit_cast (h8, r), yr, 0, 0, 0);
-		l = nl; r = nr;
-	}
-}
-
 }  // namespace mfir
 #endif
