@@ -124,6 +124,8 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 	mfir::AFrag A;
 	A.load (a.mfma_a, lane);
 	float pk_l = 0.f, pk_r = 0.f;
+	float run_l = 0.f, run_r = 0.f, tmax_prev = 3.0e38f;                 // pruning: wave-wide peaks so far; no bound on the first halo
+	uint32_t n_done = 0, n_skip = 0;
 
 	// Both word arrays start as zeros: a matrix column reads up to 9 words past its last output's window (K is
 	// padded from 55 to 56 samples) and whole columns past the end of a short tile; those products carry
@@ -170,6 +172,21 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 #pragma unroll
 		for (int n = 0; n < K; ++n) x[n] = n < rl ? x[n] : v2f{0.f, 0.f};
 		PROF_NOW (c2_); PROF_ADD (1, c2_ - c1_);
+
+		// Exact peak pruning (a.prune, as in k_fused2): |y| <= L1 * max|x| over the 48-frame window, so a tile
+		// whose max|x| (its own and the previous tile's, which holds the halo) times the largest L1 norm
+		// cannot beat what both channels already hold needs no products — the result is unchanged bit for bit.
+		// 2.5684 = the largest L1 norm of the f32 taps; the margin covers their rounding to f16 and the f32 sums.
+		bool skip = false;
+		if (a.prune && jj >= -1) {
+			float tm = 0.f;
+#pragma unroll
+			for (int n = 0; n < K; ++n) tm = fmaxf (fmaxf (tm, fabsf (x[n].x)), fabsf (x[n].y));
+			tm = mtrw::max63 (tm);
+			skip = jj >= 0 && 2.5684f * 1.002f * (float) (1 << MTR_MFMA_TAP_SHIFT) * fmaxf (tm, tmax_prev) <= fminf (run_l, run_r);
+			tmax_prev = tm;
+			n_done += jj >= 0; n_skip += skip;
+		}
 
 		// the run as {hi, lo} words behind the halo
 		{
@@ -232,7 +249,7 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 
 		PROF_NOW (c4_); PROF_ADD (3, c4_ - c3_);
 		// the interpolator: 256 output frames x 4 phases per MFMA tile and channel
-		if (jj >= 0) {
+		if (jj >= 0 && !skip) {
 			__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
 			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");            // the words of every lane are in LDS
 			const int fo = 8 * (lane & 31) + 4 * (lane >> 5);              // + (r & 3): output frame of register r in its tile
@@ -271,6 +288,7 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 				pk_l = fmaxf (pk_l, ml);
 				pk_r = fmaxf (pk_r, mr);
 			}
+			if (a.prune) { run_l = mtrw::max63 (pk_l); run_r = mtrw::max63 (pk_r); }
 		}
 
 		PROF_NOW (c5_); PROF_ADD (4, c5_ - c4_);
@@ -292,6 +310,10 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 	if (EBU && q == a.n_segs - 1 && lane == 0) {
 		st->kz[0] = k1.x; st->kz[1] = k1.y; st->kz[2] = k2.x; st->kz[3] = k2.y;
 		st->kz[4] = k3.x; st->kz[5] = k3.y; st->kz[6] = k4.x; st->kz[7] = k4.y;
+	}
+	if (a.prune && lane == 0 && a.prune_stats) {
+		atomicAdd (&a.prune_stats[0], n_done);
+		atomicAdd (&a.prune_stats[1], n_skip);
 	}
 	const float unscale = 1.f / (float) (1 << MTR_MFMA_TAP_SHIFT);       // exact
 	pk_l = mtrw::max63 (pk_l) * unscale;

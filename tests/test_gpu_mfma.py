@@ -92,3 +92,31 @@ def test_mfma_layout_truepeak_only(M, oracle):
     _, p5, _ = _run(M, x, [T], meters=M.METER_TRUEPEAK, tune_layout=5)
     for s in range(5):
         assert np.all(np.abs(_db(p5[s], oracle.tp(x[s], 48000.0, 8192))) <= 0.01), s
+
+
+def test_mfma_layout_exact_pruning_changes_nothing_but_time(M):
+    """tune_prune in layout 5 skips the products of tiles whose L1 * max|x| cannot beat the running peak: the
+    peaks must be bit-identical to the unpruned layout-5 run, on signals that prune a lot and nothing."""
+    import _signals as sig
+    T = 48000 * 8
+    loud_then_quiet = sig.lcg_noise(T, 5, 0.5)
+    loud_then_quiet[48000:] *= np.float32(0.125)
+    ramp_up = (sig.lcg_noise(T, 6, 0.5) * np.linspace(0.05, 1.0, T, dtype=np.float32)[:, None]).astype(np.float32)
+    steady = sig.lcg_noise(T, 7, 0.5)
+    spike = np.zeros((T, 2), np.float32)
+    spike[T // 2, 0] = 1.0
+    spike[T - 30, 1] = -0.75
+    x = np.stack([loud_then_quiet, ramp_up, steady, spike])
+    res = {}
+    for prune in (0, 1):
+        for segs in (0, 4):
+            with M.Engine(4, 48000.0, M.METER_EBU | M.METER_TRUEPEAK, tune_layout=5, tune_prune=prune, tune_segments=segs) as e:
+                e.integr_start()
+                for a, b in ((0, 100000), (100000, T)):
+                    e.process(x[:, a:b])
+                res[prune, segs] = (e.truepeak(), e.out9(), e.prune_stats())
+    for segs in (0, 4):
+        assert np.array_equal(res[0, segs][0], res[1, segs][0])
+        assert np.array_equal(res[0, segs][1], res[1, segs][1])
+    considered, skipped = res[1, 0][2]
+    assert considered > 0 and skipped > 0.2 * considered          # streams 0 and 3 are mostly prunable
