@@ -42,11 +42,13 @@ extern "C" {
 #define MTR_METER_TPBALLIST  0x08u  /* TruePeakdsp::process: PPM-style ballistics   (jmeters/truepeakdsp.cc:41-99) */
 #define MTR_METER_BITSTATS   0x10u  /* float_stats                                   (src/bitmeter.c:63-105) */
 #define MTR_METER_SIGDIST    0x20u  /* signal distribution histogram                (src/sigdistlv2.c:303-318) */
+#define MTR_METER_DR14       0x40u  /* DR-14 dynamic range (dr_operation_mode)      (src/dr14.c:283-352, 394-412) */
 
 #define MTR_HIST_LEN   751          /* src/uris.h:45  HIST_LEN */
 #define MTR_NBANDS     30           /* src/spectrumlv2.c:33  FILTER_COUNT */
 #define MTR_BIM_LAST   584          /* src/uris.h:60 */
 #define MTR_DIST_BIN   361          /* src/uris.h:47 */
+#define MTR_DR_HISTBINS 8000        /* src/dr14.c:43 */
 
 typedef struct mtr_engine mtr_engine;
 
@@ -152,6 +154,18 @@ int  mtr_engine_sigdist (mtr_engine* e, uint32_t first, uint32_t count,
                          int32_t* bins, int32_t* peak, double* moments, int64_t* n);
 /* replaces: bim_reset (src/bitmeter.c:47-60) and the SDH reset */
 int  mtr_engine_intstat_reset (mtr_engine* e);
+
+/* DR-14 for a batch of tracks (MTR_METER_DR14; 1 or 2 channels).  Replaces what dr14_run leaves on the dr14
+ * plugins' ports in dr_operation_mode (src/dr14.c:413-451): m_rms = the score of dr14_calc_rms_score, m_peak = the
+ * second-highest window peak in dB (LV2dr14::m_peak, the one that enters dr — the plugin's m_peak PORT shows the
+ * true-peak maximum, which is MTR_METER_TPBALLIST's tpb_peak), dr [c] = clamp (min (0, m_peak) - m_rms, 1, 20) or 21 while undefined,
+ * dr_total = the same of the mean over the valid channels, block_count = 3 * windows counted. */
+typedef struct mtr_dr14_result {
+	float m_rms[2], m_peak[2], dr[2], dr_total, block_count;
+} mtr_dr14_result;
+int  mtr_engine_dr14_results (mtr_engine* e, uint32_t first, uint32_t count, mtr_dr14_result* out);
+/* replaces: reset_peaks (src/dr14.c:245-260) */
+int  mtr_engine_dr14_reset (mtr_engine* e);
 
 /* ---- multi-GPU aggregate ---------------------------------------------------- */
 

@@ -77,6 +77,11 @@ struct mtr_engine {
 	DevBuf<float>    agg_max;
 	DevBuf<mtr_bitstats_state> bim;
 	DevBuf<mtr_sigdist_state>  sdh;
+	DevBuf<mtr_dr14_state>     dr_state;
+	DevBuf<uint32_t>           dr_hist;       // [S][C][8000]
+	DevBuf<double>             dr_sum;        // [S][pieces][2]
+	DevBuf<float>              dr_peak;
+	uint64_t                   dr_scnt = 0;   // samples in the open window (all streams run in lock step)
 	DevBuf<float>    fir_g;         // [3][48] taps in device memory
 	DevBuf<float>    fir_pmq;       // [3][24] the same in mirror-symmetric form (ballistics kernel)
 	DevBuf<uint16_t> mfma_a;        // layout 5: A fragments of the MFMA interpolator (mtr_mfma_fir.h)
@@ -313,6 +318,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
 	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release (); e->mfma_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
+	e->dr_state.release (); e->dr_hist.release (); e->dr_sum.release (); e->dr_peak.release ();
 	delete e;
 }
 
@@ -336,7 +342,57 @@ int mtr_engine_reset (mtr_engine* e)
 	e->integr = false;
 	e->hist_cur = 0;
 	e->last_n_frag = 0;
+	if (e->cfg.meters & MTR_METER_DR14) { const int drc = mtr_engine_dr14_reset (e); if (drc) return drc; }
 	if (e->cfg.meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) return mtr_engine_intstat_reset (e);
+	return MTR_OK;
+}
+
+int mtr_engine_dr14_reset (mtr_engine* e)
+{
+	if (!e || !(e->cfg.meters & MTR_METER_DR14)) return fail (MTR_ERR_ARG, "no DR14 in this engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	const uint32_t S = e->cfg.n_streams;
+	if (e->dr_state.reserve (S) || e->dr_hist.reserve ((size_t) S * e->cfg.n_channels * MTR_DR_HISTBINS))
+		return fail (MTR_ERR_NOMEM, "hipMalloc DR14 state");
+	std::vector<mtr_dr14_state> h (S);
+	memset (h.data (), 0, S * sizeof (mtr_dr14_state));
+	for (auto& v : h) for (int c = 0; c < 2; ++c) { v.m_rms[c] = -81.f; v.m_peak[c] = -81.f; }   // dr14.c:247-248
+	HIPCHK (hipStreamSynchronize (e->last_stream));
+	HIPCHK (hipMemcpy (e->dr_state.p, h.data (), S * sizeof (mtr_dr14_state), hipMemcpyHostToDevice));
+	HIPCHK (hipMemset (e->dr_hist.p, 0, (size_t) S * e->cfg.n_channels * MTR_DR_HISTBINS * sizeof (uint32_t)));
+	e->dr_scnt = 0;
+	return MTR_OK;
+}
+
+int mtr_engine_dr14_results (mtr_engine* e, uint32_t first, uint32_t count, mtr_dr14_result* out)
+{
+	if (!e || !out || !(e->cfg.meters & MTR_METER_DR14)) return fail (MTR_ERR_ARG, "no DR14 in this engine");
+	if ((uint64_t) first + count > e->cfg.n_streams) return fail (MTR_ERR_ARG, "stream range");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	HIPCHK (hipStreamSynchronize (e->last_stream));
+	std::vector<mtr_dr14_state> h (count);
+	HIPCHK (hipMemcpy (h.data (), e->dr_state.p + first, count * sizeof (mtr_dr14_state), hipMemcpyDeviceToHost));
+	const int C = (int) e->cfg.n_channels;
+	for (uint32_t i = 0; i < count; ++i) {
+		mtr_dr14_result& r = out[i];
+		memset (&r, 0, sizeof (r));
+		float total = 0.f;
+		int valid = 0;
+		for (int c = 0; c < C; ++c) {                          // dr14.c:430-441
+			const float rdb = h[i].m_rms[c], pdb = h[i].m_peak[c];
+			const float dr = (0.f < pdb ? 0.f : pdb) - rdb;
+			const bool ok = rdb > -80.f && pdb > -80.f;
+			if (ok) { total += dr; ++valid; }
+			const float cl = 20.f < dr ? 20.f : dr;
+			r.dr[c] = ok ? (1.f > cl ? 1.f : cl) : 21.f;
+			r.m_rms[c] = rdb; r.m_peak[c] = pdb;
+		}
+		if (C > 1) {                                           // :443-450
+			if (valid > 0) { const float m = total / (float) valid; const float cl = 20.f < m ? 20.f : m; r.dr_total = 1.f > cl ? 1.f : cl; }
+			else r.dr_total = 21.f;
+		}
+		r.block_count = 3.0f * (float) h[i].num_fragments;
+	}
 	return MTR_OK;
 }
 
@@ -580,6 +636,21 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		if (mtr_launch_bitstats (d_audio, stride, n_frames, e->bim.p, S, st)) return fail (MTR_ERR_HIP, "k_bitstats launch");
 	if (e->cfg.meters & MTR_METER_SIGDIST)
 		if (mtr_launch_sigdist (d_audio, stride, n_frames, e->sdh.p, S, st)) return fail (MTR_ERR_HIP, "k_sigdist launch");
+	if (e->cfg.meters & MTR_METER_DR14) {
+		mtr_dr14_args da;
+		da.audio = d_audio; da.stride = stride; da.n_frames = n_frames;
+		da.window = (uint64_t) rintf (e->cfg.sample_rate * 3.0f) + 1;       // dr14.c:155, :404
+		da.e0 = da.window - e->dr_scnt;
+		const uint64_t tot = e->dr_scnt + n_frames;
+		da.n_windows = (uint32_t) (tot / da.window);
+		da.n_pieces = da.n_windows + (tot % da.window ? 1 : 0);
+		da.n_streams = S; da.n_channels = e->cfg.n_channels;
+		if (e->dr_sum.reserve ((size_t) S * da.n_pieces * 2) || e->dr_peak.reserve ((size_t) S * da.n_pieces * 2))
+			return fail (MTR_ERR_NOMEM, "hipMalloc DR14 pieces");
+		da.state = e->dr_state.p; da.hist = e->dr_hist.p; da.piece_sum = e->dr_sum.p; da.piece_peak = e->dr_peak.p;
+		if (mtr_launch_dr14 (da, st)) return fail (MTR_ERR_HIP, "k_dr14 launch");
+		e->dr_scnt = tot % da.window;
+	}
 	const bool tpb = e->cfg.meters & MTR_METER_TPBALLIST;
 	if (tpb) {
 		mtr_tpb_args ta;

@@ -94,6 +94,24 @@ typedef struct mtr_sigdist_state {
 	unsigned long long last[MTR_DIST_BIN];   /* 1-based index of the last sample per bin (peak tie-break) */
 } mtr_sigdist_state;
 
+/* DR-14 per-stream state (src/dr14.c LV2dr14: rms_sum, peak_cur, peak_hist, m_rms, m_peak, num_fragments) */
+typedef struct mtr_dr14_state {
+	float    rms_sum[2], peak_cur[2], peak_hist[2][2], m_rms[2], m_peak[2];
+	uint32_t num_fragments;
+} mtr_dr14_state;
+
+typedef struct mtr_dr14_args {
+	const float*    audio;        /* [S][stride][C] */
+	uint64_t        stride, n_frames;
+	uint64_t        window;       /* n_sample_cnt + 1 samples close a window (dr14.c:404) */
+	uint64_t        e0;           /* call frame at which the window open on entry closes */
+	uint32_t        n_streams, n_channels, n_pieces, n_windows;
+	mtr_dr14_state* state;        /* [S] */
+	uint32_t*       hist;         /* [S][C][8000] */
+	double*         piece_sum;    /* [S][n_pieces][2] */
+	float*          piece_peak;   /* [S][n_pieces][2] */
+} mtr_dr14_args;
+
 typedef struct mtr_tpb_args mtr_tpb_args;
 struct mtr_tpb_args {
 	const float*    audio;        /* [S][stride][C] */
@@ -125,6 +143,7 @@ int  mtr_launch_fused (int run, bool ebu, bool tp, const mtr_fused_args& a, uint
 int  mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kw (int run, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kwtp (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
+int  mtr_launch_dr14 (const mtr_dr14_args& a, void* stream);
 int  mtr_fused2_upload_taps (const float* g144);
 int  mtr_fused_upload_taps (const float* g144);    /* [3][48] full 48-tap kernels of phases 1..3 */
 int  mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,

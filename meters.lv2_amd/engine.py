@@ -12,7 +12,7 @@ import re
 import numpy as np
 
 METER_EBU, METER_TRUEPEAK, METER_SPECTR30, METER_TPBALLIST = 0x01, 0x02, 0x04, 0x08
-METER_BITSTATS, METER_SIGDIST = 0x10, 0x20
+METER_BITSTATS, METER_SIGDIST, METER_DR14 = 0x10, 0x20, 0x40
 BIM_LAST, DIST_BIN = 584, 361
 HIST_LEN, NBANDS = 751, 30
 
@@ -29,6 +29,12 @@ class _Config(C.Structure):
                 ("n_channels", C.c_uint32), ("sample_rate", C.c_float), ("device", C.c_int32),
                 ("max_frames", C.c_uint32), ("tune_run", C.c_uint32), ("tune_segments", C.c_uint32),
                 ("tune_layout", C.c_uint32), ("tune_fir", C.c_uint32), ("tune_prune", C.c_uint32)]
+
+
+class Dr14Result(C.Structure):
+    """mtr_dr14_result: what dr14_run leaves on the dr14 plugins' ports in dr_operation_mode."""
+    _fields_ = [("m_rms", C.c_float * 2), ("m_peak", C.c_float * 2), ("dr", C.c_float * 2),
+                ("dr_total", C.c_float), ("block_count", C.c_float)]
 
 
 class StreamResult(C.Structure):
@@ -86,6 +92,8 @@ def _load():
     L.mtr_engine_bitstats.argtypes = [vp, u32, u32, vp, vp, vp]
     L.mtr_engine_sigdist.argtypes = [vp, u32, u32, vp, vp, vp, vp]
     L.mtr_engine_intstat_reset.argtypes = [vp]
+    L.mtr_engine_dr14_results.argtypes = [vp, u32, u32, vp]
+    L.mtr_engine_dr14_reset.argtypes = [vp]
     L.mtr_engine_prune_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_hist_loudness.argtypes = [vp, vp] + [C.POINTER(f32)] * 5
     L.mtr_hist_loudness.restype = None
@@ -251,6 +259,15 @@ class Engine:
         mm = np.zeros((count, 2), np.float32)
         _check(lib.mtr_engine_bitstats(self._h, first, count, hist.ctypes.data, cnt.ctypes.data, mm.ctypes.data), "bitstats")
         return dict(hist=hist, counters=cnt, vmin=mm[:, 0], vmax=mm[:, 1])
+
+    def dr14(self, first=0, count=None):
+        count = self.n_streams - first if count is None else count
+        out = (Dr14Result * count)()
+        _check(lib.mtr_engine_dr14_results(self._h, first, count, out), "dr14_results")
+        return out
+
+    def dr14_reset(self):
+        _check(lib.mtr_engine_dr14_reset(self._h), "dr14_reset")
 
     def sigdist(self, first=0, count=None):
         count = self.n_streams - first if count is None else count
