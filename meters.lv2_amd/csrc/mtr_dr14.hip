@@ -39,12 +39,27 @@ __global__ __launch_bounds__ (NT) void k_dr14_sums (const mtr_dr14_args a)
 	const float* const src = a.audio + (size_t) s * a.stride * C;
 	double sl = 0, sr = 0;
 	float pl = 0.f, pr = 0.f;                                  // dr14.c:401: max (peak_cur, v), signed v, from 0
-	for (uint64_t f = b0 + threadIdx.x; f < b1; f += NT) {
-		if (C == 2) {
+	if (C == 2) {
+		// 16-byte loads: two frames per lane; a piece that starts on an odd frame of the buffer gives its first
+		// frame (and one that ends on an odd frame its last) to a single lane
+		const uint64_t odd = ((size_t) s * a.stride + b0 + (reinterpret_cast<size_t> (a.audio) >> 3)) & 1;
+		const uint64_t h0 = b0 + (odd && b0 < b1 ? 1 : 0);
+		const uint64_t np = (b1 - h0) >> 1;                    // whole pairs
+		auto one = [&] (uint64_t f) {
 			const float2 v = *reinterpret_cast<const float2*> (src + 2 * f);
 			sl += (double) (v.x * v.x); sr += (double) (v.y * v.y);
 			pl = fmaxf (pl, v.x); pr = fmaxf (pr, v.y);
-		} else {
+		};
+		if (threadIdx.x == 0 && h0 > b0) one (b0);
+		if (threadIdx.x == 1 && h0 + 2 * np < b1) one (b1 - 1);
+		const float4* const p4 = reinterpret_cast<const float4*> (src + 2 * h0);
+		for (uint64_t i = threadIdx.x; i < np; i += NT) {
+			const float4 v = p4[i];
+			sl += (double) (v.x * v.x) + (double) (v.z * v.z); sr += (double) (v.y * v.y) + (double) (v.w * v.w);
+			pl = fmaxf (pl, fmaxf (v.x, v.z)); pr = fmaxf (pr, fmaxf (v.y, v.w));
+		}
+	} else {
+		for (uint64_t f = b0 + threadIdx.x; f < b1; f += NT) {
 			const float v = src[f];
 			sl += (double) (v * v);
 			pl = fmaxf (pl, v);
