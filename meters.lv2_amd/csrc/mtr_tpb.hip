@@ -13,7 +13,8 @@
 // (first version: one wave per stream, one lane walking 256 values per 64 frames: 543 ms per
 // 31.5 GB; this one: see DESIGN.md):
 //
-//   * a workgroup of eight waves owns 64 streams, lane = stream, both channels packed in one v2f;
+//   * a workgroup of eight waves owns 64 streams, lane = stream, both channels packed in one v2f (32 streams
+//     with two lanes per stream in the interpolators when the batch would otherwise leave CUs idle);
 //   * wave 0 is the recurrence: 64 independent (z1, z2, m, p) chains, 4 steps per frame, on the
 //     previous chunk's values.  It is the serial chain, so it keeps a SIMD to itself (the wave's
 //     SIMD id is read from HW_ID; the wave that shares it only fetches);
@@ -53,7 +54,8 @@ constexpr int NW = 8;                    // waves: wave 0 is the recurrence, the
 constexpr int R = 2;                     // frames per interpolation item
 constexpr int NGRP = 6;                  // items per chunk: one per interpolator wave when two waves share a SIMD
 constexpr int F = NGRP * R;              // 12 frames per chunk
-constexpr int NS = 64;                   // streams per workgroup
+// streams per workgroup: 64 (lane = stream in every role) or, for batches that would otherwise leave CUs idle, 32
+// (two lanes per stream in the interpolators, one frame of the item each; half the recurrence wave idles)
 // Input rows live in a ring of six chunks per stream: the 48-frame window (four chunks) of the chunk being
 // interpolated, that chunk, and the one being fetched.  Every frame is stored twice, RING slots apart, so
 // any 60-slot window is contiguous in LDS and the interpolator's offsets stay compile-time constants.
@@ -61,9 +63,8 @@ constexpr int RING = 6 * F;              // 72 slots; frame f <-> slot f mod 72 
 constexpr int IN_STRIDE = 2 * RING + 1;  // 145
 constexpr int OV_STRIDE = 4 * F + 1;     // 49 slots: slot 4 f + q <-> phase q of frame c0 + f
 constexpr int NTHREADS = 64 * NW;
-constexpr int NLOAD = NS * F / 64;       // 12 wave-wide loads bring one chunk of all 64 rows
-constexpr int LPW = (NLOAD + NW - 2) / (NW - 1);   // at most 2 of them per fetching wave
-static_assert (IN_STRIDE % 2 == 1 && OV_STRIDE % 2 == 1 && 48 % F == 0 && (NS * F) % 64 == 0, "odd lane strides; whole chunks of history");
+constexpr int LPW = (64 * F / 64 + NW - 2) / (NW - 1);   // wave-wide loads per fetching wave and chunk: at most 2
+static_assert (IN_STRIDE % 2 == 1 && OV_STRIDE % 2 == 1 && 48 % F == 0, "odd lane strides; whole chunks of history");
 
 __device__ __forceinline__ v2f vabs (v2f v) { return v2f{fabsf (v.x), fabsf (v.y)}; }
 
@@ -91,18 +92,19 @@ __device__ __forceinline__ void tap_fma (v2f& acc, const v2f* t, v2f x)
 }
 
 constexpr int G = 6;                     // mirror pairs per tap group
-constexpr int NW_G = R + G - 1;          // window slots a group needs on either side
-
-template <int G0>
+// RL = frames per lane of an item (2, or 1 when two lanes share a stream); a group needs RL + G - 1 window
+// slots on either side
+template <int G0, int RL>
 __device__ __forceinline__ void group_load (const v2f* xs, v2f* L, v2f* B)
 {
+	constexpr int NW_G = RL + G - 1;
 	const v2f* const xl = xs + 1 + G0;
 	const v2f* const xr = xs + 48 - G0 - (G - 1);
 #pragma unroll
 	for (int j = 0; j < NW_G; ++j) { L[j] = xl[j]; B[j] = xr[j]; }
 }
 
-template <int G0>
+template <int G0, int RL>
 __device__ __forceinline__ void group_mac (const v2f* L, const v2f* B, const Taps& tp, v2f* aS, v2f* aD, v2f* aQ)
 {
 #define MTR_TPB_TAP(k)                                                                   \
@@ -114,34 +116,36 @@ __device__ __forceinline__ void group_mac (const v2f* L, const v2f* B, const Tap
 		tap_fma<G0 + k> (aQ[r], tp.q, sv);                                               \
 	}
 #pragma unroll
-	for (int r = 0; r < R; ++r) { MTR_TPB_TAP (0) MTR_TPB_TAP (1) MTR_TPB_TAP (2) MTR_TPB_TAP (3) MTR_TPB_TAP (4) MTR_TPB_TAP (5) }
+	for (int r = 0; r < RL; ++r) { MTR_TPB_TAP (0) MTR_TPB_TAP (1) MTR_TPB_TAP (2) MTR_TPB_TAP (3) MTR_TPB_TAP (4) MTR_TPB_TAP (5) }
 #undef MTR_TPB_TAP
 }
 
+template <int RL>
 __device__ __forceinline__ void interpolate (const v2f* xs, const Taps& tp, v2f* out)
 {
-	v2f aS[R], aD[R], aQ[R];
+	constexpr int NW_G = RL + G - 1;
+	v2f aS[RL], aD[RL], aQ[RL];
 #pragma unroll
-	for (int r = 0; r < R; ++r) { aS[r] = 0; aD[r] = 0; aQ[r] = 0; }
+	for (int r = 0; r < RL; ++r) { aS[r] = 0; aD[r] = 0; aQ[r] = 0; }
 	// the LDS reads of a group are issued a whole group of arithmetic ahead (left to itself the scheduler
 	// sinks them next to their first use, and with two waves per SIMD that latency is not covered)
 	v2f L0[NW_G], B0[NW_G], L1[NW_G], B1[NW_G];
-	group_load<0> (xs, L0, B0);
-	group_load<6> (xs, L1, B1);
+	group_load<0, RL> (xs, L0, B0);
+	group_load<6, RL> (xs, L1, B1);
 	__builtin_amdgcn_sched_barrier (0);
-	group_mac<0> (L0, B0, tp, aS, aD, aQ);
+	group_mac<0, RL> (L0, B0, tp, aS, aD, aQ);
 	__builtin_amdgcn_sched_barrier (0);
-	group_load<12> (xs, L0, B0);
+	group_load<12, RL> (xs, L0, B0);
 	__builtin_amdgcn_sched_barrier (0);
-	group_mac<6> (L1, B1, tp, aS, aD, aQ);
+	group_mac<6, RL> (L1, B1, tp, aS, aD, aQ);
 	__builtin_amdgcn_sched_barrier (0);
-	group_load<18> (xs, L1, B1);
+	group_load<18, RL> (xs, L1, B1);
 	__builtin_amdgcn_sched_barrier (0);
-	group_mac<12> (L0, B0, tp, aS, aD, aQ);
+	group_mac<12, RL> (L0, B0, tp, aS, aD, aQ);
 	__builtin_amdgcn_sched_barrier (0);
-	group_mac<18> (L1, B1, tp, aS, aD, aQ);
+	group_mac<18, RL> (L1, B1, tp, aS, aD, aQ);
 #pragma unroll
-	for (int r = 0; r < R; ++r) {
+	for (int r = 0; r < RL; ++r) {
 		out[4 * r + 0] = vabs (xs[24 + r]);          // phase 0 is the identity: x[n - 24]
 		out[4 * r + 1] = vabs (aS[r] + aD[r]);
 		out[4 * r + 2] = vabs (aQ[r]);
@@ -149,14 +153,18 @@ __device__ __forceinline__ void interpolate (const v2f* xs, const Taps& tp, v2f*
 	}
 }
 
-template <int C>      // channels: 2 = interleaved stereo, 1 = mono (the right half of every v2f stays zero)
+template <int C, int NS>   // channels: 2 = interleaved stereo, 1 = mono (the right half of every v2f stays zero); streams per workgroup
 __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 {
+	static_assert (NS == 64 || NS == 32, "one or two lanes per stream");
+	constexpr int RL = R * NS / 64;                                      // frames per lane of an interpolation item
+	constexpr int NLOAD = NS * F / 64;                                   // wave-wide loads that bring one chunk of all rows
 	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
 	v2f* const in_buf = reinterpret_cast<v2f*> (smem);                   // [NS][IN_STRIDE]
 	v2f* const ov_buf = in_buf + NS * IN_STRIDE;                         // [2][NS][OV_STRIDE]
 	const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
 	const uint32_t s0 = blockIdx.x * NS;
+	const int srow = lane & (NS - 1), half = lane / NS;                  // interpolators and recurrence: this lane's stream; its half of an item
 	const int64_t n_chunks = (int64_t) ((a.n_frames + F - 1) / F);
 	const bool fir = wid != 0;
 
@@ -229,9 +237,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 
 	// ---- recurrence wave: state of stream s0 + lane ----
 	v2f z1 = 0, z2 = 0, m = 0, p = 0;
-	const uint32_t sl = s0 + (uint32_t) lane;
+	const uint32_t sl = s0 + (uint32_t) srow;
+	const bool owner = lane < NS && sl < a.n_streams;                    // the lane that carries this stream's chain
 	mtr_stream_state* const st = a.state + (sl < a.n_streams ? sl : 0);
-	if (!fir && sl < a.n_streams) {
+	if (!fir && owner) {
 		z1 = v2f{st->tpb_z1[0], st->tpb_z1[1]};
 		z2 = v2f{st->tpb_z2[0], st->tpb_z2[1]};
 		z1 = v2f{z1.x > 20 ? 20 : (z1.x < 0 ? 0 : z1.x), z1.y > 20 ? 20 : (z1.y < 0 ? 0 : z1.y)};   // truepeakdsp.cc:54-55
@@ -276,12 +285,12 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 			PROF_ADD (2, cf_ - c0_);
 			if (t < n_chunks && item0 >= 0) {
 				for (int g = item0; g < NGRP; g += n_interp) {
-					const v2f* const xs = in_buf + lane * IN_STRIDE + rd * F + R * g;
-					v2f o[4 * R];
-					interpolate (xs, taps, o);
-					v2f* const dst = ov_buf + (t & 1) * NS * OV_STRIDE + lane * OV_STRIDE + 4 * R * g;
+					const v2f* const xs = in_buf + srow * IN_STRIDE + rd * F + R * g + RL * half;
+					v2f o[4 * RL];
+					interpolate<RL> (xs, taps, o);
+					v2f* const dst = ov_buf + (t & 1) * NS * OV_STRIDE + srow * OV_STRIDE + 4 * (R * g + RL * half);
 #pragma unroll
-					for (int i = 0; i < 4 * R; ++i) dst[i] = o[i];
+					for (int i = 0; i < 4 * RL; ++i) dst[i] = o[i];
 				}
 			}
 			PROF_NOW (c1_);
@@ -292,7 +301,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		} else if (t > 0) {
 			const int64_t c0 = (t - 1) * F;
 			const int nf = (int) min ((int64_t) F, (int64_t) a.n_frames - c0);
-			const v2f* const ov = ov_buf + ((t - 1) & 1) * NS * OV_STRIDE + lane * OV_STRIDE;
+			const v2f* const ov = ov_buf + ((t - 1) & 1) * NS * OV_STRIDE + srow * OV_STRIDE;
 			// the values do not depend on the state: fetched a frame ahead of the chain that consumes them
 			v2f v[4] = { ov[0], ov[1], ov[2], ov[3] };
 #pragma unroll
@@ -329,7 +338,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	}
 #endif
 
-	if (!fir && sl < a.n_streams) {
+	if (!fir && owner) {
 		st->tpb_z1[0] = z1.x + 1e-20f; st->tpb_z1[1] = z1.y + 1e-20f;     // truepeakdsp.cc:86-87
 		st->tpb_z2[0] = z2.x + 1e-20f; st->tpb_z2[1] = z2.y + 1e-20f;
 		st->tpb_m[0] = m.x * a.g; st->tpb_m[1] = m.y * a.g;               // :89, then read (m, p)
@@ -354,17 +363,26 @@ __global__ void k_history_mono (const float* audio, uint64_t stride, uint64_t n_
 
 int mtr_launch_tpb (const mtr_tpb_args& a, void* stream)
 {
-	const size_t lds = (size_t) NS * (IN_STRIDE + 2 * OV_STRIDE) * sizeof (v2f);      // 110 KiB: one workgroup per CU
+	// 64 streams per workgroup (121 KiB of LDS: one workgroup per CU) when that fills the chip; 32 otherwise
+	const bool narrow = (a.n_streams + 63) / 64 <= 128;
+	const int ns = narrow ? 32 : 64;
+	const size_t lds = (size_t) ns * (IN_STRIDE + 2 * OV_STRIDE) * sizeof (v2f);
+	const size_t lds64 = (size_t) 64 * (IN_STRIDE + 2 * OV_STRIDE) * sizeof (v2f);
 	static bool raised = false;
 	if (!raised) {
-		(void) hipFuncSetAttribute ((const void*) k_tpb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		(void) hipFuncSetAttribute ((const void*) k_tpb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		(void) hipFuncSetAttribute ((const void*) k_tpb<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds64);
+		(void) hipFuncSetAttribute ((const void*) k_tpb<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds64);
 		raised = true;
 	}
-	if (a.n_channels == 2)
-		hipLaunchKernelGGL (k_tpb<2>, dim3 ((a.n_streams + NS - 1) / NS), dim3 (NTHREADS), lds, (hipStream_t) stream, a);
-	else
-		hipLaunchKernelGGL (k_tpb<1>, dim3 ((a.n_streams + NS - 1) / NS), dim3 (NTHREADS), lds, (hipStream_t) stream, a);
+	const dim3 grid ((a.n_streams + ns - 1) / ns);
+	hipStream_t st = (hipStream_t) stream;
+	if (a.n_channels == 2) {
+		if (narrow) hipLaunchKernelGGL ((k_tpb<2, 32>), grid, dim3 (NTHREADS), lds, st, a);
+		else        hipLaunchKernelGGL ((k_tpb<2, 64>), grid, dim3 (NTHREADS), lds, st, a);
+	} else {
+		if (narrow) hipLaunchKernelGGL ((k_tpb<1, 32>), grid, dim3 (NTHREADS), lds, st, a);
+		else        hipLaunchKernelGGL ((k_tpb<1, 64>), grid, dim3 (NTHREADS), lds, st, a);
+	}
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 

@@ -380,23 +380,24 @@ def test_long_call_gate_spread_over_workgroups(M, oracle, meters):
         assert (one[4][s].hist_M_count, one[4][s].hist_S_count) == tuple(o["counts"])
 
 
-@pytest.mark.parametrize("chn", [1, 2])
-def test_truepeak_ballistics_many_streams(M, oracle, chn):
-    """The batch layout of k_tpb: 64 streams per workgroup (the last one partly filled), 16-frame chunks with a
-    ragged tail, three calls of odd sizes, mono and stereo engines; sampled streams against the oracle."""
+@pytest.mark.parametrize("chn,S,T", [(1, 131, 5003), (2, 131, 5003), (2, 8192 + 67, 1203)])
+def test_truepeak_ballistics_many_streams(M, oracle, chn, S, T):
+    """The batch layouts of k_tpb: 32 streams per workgroup (two lanes per stream in the interpolators) for
+    batches up to 8192 streams, 64 beyond; the last workgroup partly filled, 12-frame chunks with a ragged
+    tail, three calls of odd sizes, mono and stereo engines; sampled streams against the oracle."""
     import ctypes as C
     from _oracle import MoTp
-    S, T = 131, 5003
-    x = np.stack([sig.lcg_noise(T, 700 + s, 2.0 ** -(s % 4)) for s in range(S)])       # [S][T][2]
+    base = np.stack([sig.lcg_noise(T, 700 + s, 2.0 ** -(s % 4)) for s in range(131)])  # [131][T][2]
+    x = base if S == 131 else base[np.arange(S) % 131] * (1.0 + (np.arange(S) // 131)[:, None, None].astype(np.float32) / 64)
     feed = x if chn == 2 else np.ascontiguousarray(x[:, :, 0])
-    cuts = (0, 17, 2400, T)
+    cuts = (0, 17, 2400 if T > 2400 else 700, T)
     with M.Engine(S, 48000.0, M.METER_TPBALLIST, n_channels=chn) as e:
         got = []
         for a, b in zip(cuts[:-1], cuts[1:]):
             e.process(np.ascontiguousarray(feed[:, a:b]))
             r = e.results()
             got.append([[(r[s].tpb_level[c], r[s].tpb_peak[c]) for c in range(chn)] for s in range(S)])
-    for s in (0, 1, 63, 64, 65, 127, 128, 130):
+    for s in (0, 1, 31, 32, 63, 64, 65, 127, 128, 130) + ((4095, 8191, 8192, S - 1) if S > 131 else ()):
         for c in range(chn):
             ch = np.ascontiguousarray(x[s, :, c])
             t = MoTp()
