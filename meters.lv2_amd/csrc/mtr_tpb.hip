@@ -236,7 +236,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	};
 
 	// ---- recurrence wave: state of stream s0 + lane ----
-	v2f z1 = 0, z2 = 0, m = 0, p = 0;
+	v2f z1 = 0, z2 = 0, m = 0;
+	v2f pkp = 0;                                                         // raw peak of the values this lane saw
 	const uint32_t sl = s0 + (uint32_t) srow;
 	const bool owner = lane < NS && sl < a.n_streams;                    // the lane that carries this stream's chain
 	mtr_stream_state* const st = a.state + (sl < a.n_streams ? sl : 0);
@@ -291,6 +292,19 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 					v2f* const dst = ov_buf + (t & 1) * NS * OV_STRIDE + srow * OV_STRIDE + 4 * (R * g + RL * half);
 #pragma unroll
 					for (int i = 0; i < 4 * RL; ++i) dst[i] = o[i];
+					// the raw peak (truepeakdsp.cc:65: p = max (p, v)) does not depend on the chain: with 32 streams
+					// per workgroup it is taken here, off the recurrence wave, which is that shape's bound
+					const int64_t f0 = t * F + R * g + RL * half;
+#pragma unroll
+					for (int r = 0; r < RL; ++r) {
+						if (NS == 32 && f0 + r < (int64_t) a.n_frames) {
+#pragma unroll
+							for (int q = 0; q < 4; ++q) {
+								pkp.x = fmaxf (pkp.x, o[4 * r + q].x);
+								pkp.y = fmaxf (pkp.y, o[4 * r + q].y);
+							}
+						}
+					}
 				}
 			}
 			PROF_NOW (c1_);
@@ -315,7 +329,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 					for (int q = 0; q < 4; ++q) {
 						z1 = attack (z1, v[q], a.w1);
 						z2 = attack (z2, v[q], a.w2);
-						p = v2f{fmaxf (p.x, v[q].x), fmaxf (p.y, v[q].y)};
+						if (NS == 64) pkp = v2f{fmaxf (pkp.x, v[q].x), fmaxf (pkp.y, v[q].y)};
 					}
 					const v2f zz = z1 + z2;
 					m = v2f{fmaxf (m.x, zz.x), fmaxf (m.y, zz.y)};
@@ -338,7 +352,17 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	}
 #endif
 
+	// the interpolators' raw peaks per stream (non-negative floats order as unsigned ints)
+	uint32_t* const pk_sh = reinterpret_cast<uint32_t*> (in_buf);        // the input ring is spent
+	for (int i = threadIdx.x; i < 2 * NS; i += NTHREADS) pk_sh[i] = 0u;
+	__syncthreads ();
+	if (fir == (NS == 32)) {                                             // whoever tracked it (the recurrence wave at 64 streams)
+		atomicMax (&pk_sh[2 * srow], __float_as_uint (pkp.x));
+		atomicMax (&pk_sh[2 * srow + 1], __float_as_uint (pkp.y));
+	}
+	__syncthreads ();
 	if (!fir && owner) {
+		const v2f p = v2f{__uint_as_float (pk_sh[2 * srow]), __uint_as_float (pk_sh[2 * srow + 1])};
 		st->tpb_z1[0] = z1.x + 1e-20f; st->tpb_z1[1] = z1.y + 1e-20f;     // truepeakdsp.cc:86-87
 		st->tpb_z2[0] = z2.x + 1e-20f; st->tpb_z2[1] = z2.y + 1e-20f;
 		st->tpb_m[0] = m.x * a.g; st->tpb_m[1] = m.y * a.g;               // :89, then read (m, p)
