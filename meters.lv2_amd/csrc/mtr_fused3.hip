@@ -168,7 +168,8 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 		asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");    // every read has returned: the buffer is free
 		if (!INPLACE && jj + 1 < ntile) stage (jj + 1);
 		// slots past the tile hold stale data: zero them once, here, so that nothing below needs a per-frame test
-		// (a per-frame `if (n < rl)` is a lane-mask update and a branch per frame)
+		// (a per-frame `if (n < rl)` is a lane-mask update and a branch per frame; zeroing the tail in LDS
+		// before the reads instead was measured: no gain)
 #pragma unroll
 		for (int n = 0; n < K; ++n) x[n] = n < rl ? x[n] : v2f{0.f, 0.f};
 		PROF_NOW (c2_); PROF_ADD (1, c2_ - c1_);
@@ -188,8 +189,18 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 			n_done += jj >= 0; n_skip += skip;
 		}
 
+		// A pruned tile's words are never multiplied: all that is needed of them is the next tile's halo, and its 47
+		// frames are still there as f32 (in place, nothing has been written over the tile yet).
+		const bool no_words = INPLACE && skip && len >= HALO;
+		if (no_words) {
+			if (lane < HALO) {
+				const v2f h = buf[(int) (t0 & 1) + len - HALO + lane];
+				mfir::split_words (h.x, h.y, halo_l, halo_r);
+			}
+			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
 		// the run as {hi, lo} words behind the halo
-		{
+		if (!no_words) {
 			if (INPLACE) {
 				// the tile was lying over both arrays: put the halo back, and zeros into the pad behind the left array
 				if (lane < HALO) { WL[lane] = halo_l; WR[lane] = halo_r; }
@@ -294,7 +305,7 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 		PROF_NOW (c5_); PROF_ADD (4, c5_ - c4_);
 		// the next tile's halo: the last 47 frames before t0 + len sit at positions len .. len + 46
 		{
-			if (lane < HALO) { halo_l = WL[len + lane]; halo_r = WR[len + lane]; }
+			if (!no_words && lane < HALO) { halo_l = WL[len + lane]; halo_r = WR[len + lane]; }
 			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
 			if (INPLACE) {
 				if (jj + 1 < ntile) stage (jj + 1);                // over the words: they are spent
