@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8192, help="streams per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="audio seconds per stream per step")
     ap.add_argument("--meters", default="ebu+tp", choices=["ebu+tp", "ebu", "tp", "ebu+tp+spectr30", "spectr30",
-                                                           "bitstats", "sigdist", "tpb", "dr14"])
+                                                           "bitstats", "sigdist", "tpb", "dr14", "kmeter"])
     ap.add_argument("--run", type=int, default=0, help="frames per lane run (0 = engine default)")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 wave per segment, 2/3 wave-specialised, 4 K-weighting only, 5 matrix-pipe interpolator")
@@ -126,7 +126,7 @@ def main():
     meters = {"ebu+tp": M.METER_EBU | M.METER_TRUEPEAK, "ebu": M.METER_EBU, "tp": M.METER_TRUEPEAK,
               "ebu+tp+spectr30": M.METER_EBU | M.METER_TRUEPEAK | M.METER_SPECTR30,
               "spectr30": M.METER_SPECTR30, "bitstats": M.METER_BITSTATS, "sigdist": M.METER_SIGDIST,
-              "tpb": M.METER_TPBALLIST, "dr14": M.METER_DR14}[args.meters]
+              "tpb": M.METER_TPBALLIST, "dr14": M.METER_DR14, "kmeter": M.METER_KMETER}[args.meters]
     mono = bool(meters & (M.METER_BITSTATS | M.METER_SIGDIST))   # integer paths: the same buffer read as [S][2T] mono
 
     free, _ = torch.cuda.mem_get_info()
@@ -233,7 +233,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "kernel": {"spectr30": "k_bank", "bitstats": "k_bitstats", "sigdist": "k_sigdist",
-                                          "tpb": "k_tpb", "dr14": "k_dr14_sums"}.get(args.meters, "k_bank"),
+                                          "tpb": "k_tpb", "dr14": "k_dr14_sums", "kmeter": "k_kmeter_pieces"}.get(args.meters, "k_bank"),
                                "kernel_ms": k_ms}
         if mono:
             print(json.dumps(out), flush=True)

@@ -43,6 +43,7 @@ extern "C" {
 #define MTR_METER_BITSTATS   0x10u  /* float_stats                                   (src/bitmeter.c:63-105) */
 #define MTR_METER_SIGDIST    0x20u  /* signal distribution histogram                (src/sigdistlv2.c:303-318) */
 #define MTR_METER_DR14       0x40u  /* DR-14 dynamic range (dr_operation_mode)      (src/dr14.c:283-352, 394-412) */
+#define MTR_METER_KMETER     0x80u  /* Kmeterdsp: RMS + peak with hold / fall-back  (jmeters/kmeterdsp.cc:56-140) */
 
 #define MTR_HIST_LEN   751          /* src/uris.h:45  HIST_LEN */
 #define MTR_NBANDS     30           /* src/spectrumlv2.c:33  FILTER_COUNT */
@@ -166,6 +167,14 @@ typedef struct mtr_dr14_result {
 int  mtr_engine_dr14_results (mtr_engine* e, uint32_t first, uint32_t count, mtr_dr14_result* out);
 /* replaces: reset_peaks (src/dr14.c:245-260) */
 int  mtr_engine_dr14_reset (mtr_engine* e);
+
+/* Kmeterdsp for a batch (MTR_METER_KMETER; 1 or 2 channels): every process call is one Kmeterdsp::process () per
+ * channel (jmeters/kmeterdsp.cc:56-140; n mod 4 trailing frames are dropped as there).
+ * replaces: Kmeterdsp::read (rms, peak) (:148-153) — rms, peak [count][2] linear; arms the "start a new maximum"
+ * flag exactly as read () does */
+int  mtr_engine_kmeter_read (mtr_engine* e, uint32_t first, uint32_t count, float* rms, float* peak);
+/* replaces: Kmeterdsp::reset (:142-146) */
+int  mtr_engine_kmeter_reset (mtr_engine* e);
 
 /* ---- multi-GPU aggregate ---------------------------------------------------- */
 

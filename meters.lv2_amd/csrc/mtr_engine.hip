@@ -82,6 +82,12 @@ struct mtr_engine {
 	DevBuf<double>             dr_sum;        // [S][pieces][2]
 	DevBuf<float>              dr_peak;
 	uint64_t                   dr_scnt = 0;   // samples in the open window (all streams run in lock step)
+	DevBuf<mtr_kmeter_state>   km_state;      // [S][2]
+	DevBuf<double>             km_pw, km_piece;
+	DevBuf<float>              km_max;
+	double                     km_pw1[3];
+	uint32_t                   km_fpp = 0;
+	float                      km_fall = 0.f;
 	DevBuf<float>    fir_g;         // [3][48] taps in device memory
 	DevBuf<float>    fir_pmq;       // [3][24] the same in mirror-symmetric form (ballistics kernel)
 	DevBuf<uint16_t> mfma_a;        // layout 5: A fragments of the MFMA interpolator (mtr_mfma_fir.h)
@@ -319,6 +325,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release (); e->mfma_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
 	e->dr_state.release (); e->dr_hist.release (); e->dr_sum.release (); e->dr_peak.release ();
+	e->km_state.release (); e->km_pw.release (); e->km_piece.release (); e->km_max.release ();
 	delete e;
 }
 
@@ -343,7 +350,35 @@ int mtr_engine_reset (mtr_engine* e)
 	e->hist_cur = 0;
 	e->last_n_frag = 0;
 	if (e->cfg.meters & MTR_METER_DR14) { const int drc = mtr_engine_dr14_reset (e); if (drc) return drc; }
+	if (e->cfg.meters & MTR_METER_KMETER) { const int krc = mtr_engine_kmeter_reset (e); if (krc) return krc; e->km_fpp = 0; e->km_fall = 0.f; }
 	if (e->cfg.meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) return mtr_engine_intstat_reset (e);
+	return MTR_OK;
+}
+
+int mtr_engine_kmeter_reset (mtr_engine* e)
+{
+	if (!e || !(e->cfg.meters & MTR_METER_KMETER)) return fail (MTR_ERR_ARG, "no KMETER in this engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	const size_t n = (size_t) e->cfg.n_streams * 2;
+	if (e->km_state.reserve (n) || e->km_pw.reserve (27)) return fail (MTR_ERR_NOMEM, "hipMalloc KMETER state");
+	double pw[27];
+	mtr_kmeter_powers (9.72f / e->cfg.sample_rate, pw, e->km_pw1);       // kmeterdsp.cc:52
+	HIPCHK (hipStreamSynchronize (e->last_stream));
+	HIPCHK (hipMemcpy (e->km_pw.p, pw, sizeof (pw), hipMemcpyHostToDevice));
+	HIPCHK (hipMemset (e->km_state.p, 0, n * sizeof (mtr_kmeter_state)));   // :142-146
+	return MTR_OK;
+}
+
+int mtr_engine_kmeter_read (mtr_engine* e, uint32_t first, uint32_t count, float* rms, float* peak)
+{
+	if (!e || !rms || !peak || !(e->cfg.meters & MTR_METER_KMETER)) return fail (MTR_ERR_ARG, "no KMETER in this engine");
+	if ((uint64_t) first + count > e->cfg.n_streams) return fail (MTR_ERR_ARG, "stream range");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	HIPCHK (hipStreamSynchronize (e->last_stream));
+	std::vector<mtr_kmeter_state> h ((size_t) count * 2);
+	HIPCHK (hipMemcpy (h.data (), e->km_state.p + (size_t) first * 2, h.size () * sizeof (mtr_kmeter_state), hipMemcpyDeviceToHost));
+	for (size_t i = 0; i < h.size (); ++i) { rms[i] = h[i].rms; peak[i] = h[i].peak; h[i].flag = 1; }
+	HIPCHK (hipMemcpy (e->km_state.p + (size_t) first * 2, h.data (), h.size () * sizeof (mtr_kmeter_state), hipMemcpyHostToDevice));
 	return MTR_OK;
 }
 
@@ -650,6 +685,26 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		da.state = e->dr_state.p; da.hist = e->dr_hist.p; da.piece_sum = e->dr_sum.p; da.piece_peak = e->dr_peak.p;
 		if (mtr_launch_dr14 (da, st)) return fail (MTR_ERR_HIP, "k_dr14 launch");
 		e->dr_scnt = tot % da.window;
+	}
+	if (e->cfg.meters & MTR_METER_KMETER) {
+		if (n_frames >= 0x7fffffffull) return fail (MTR_ERR_ARG, "KMETER: n_frames per call must be < 2^31 - 1 (the reference's int n)");
+		mtr_kmeter_args ka;
+		ka.audio = d_audio; ka.stride = stride; ka.n_groups = n_frames / 4;
+		ka.n_streams = S; ka.n_channels = e->cfg.n_channels;
+		ka.n_pieces = mtr_kmeter_pieces (ka.n_groups);
+		if (e->km_fpp != (uint32_t) n_frames) {                              // kmeterdsp.cc:60-65
+			e->km_fall = powf (10.0f, -0.05f * 15.0f * ((float) n_frames / e->cfg.sample_rate));
+			e->km_fpp = (uint32_t) n_frames;
+		}
+		ka.fpp = e->km_fpp; ka.fall = e->km_fall;
+		ka.hold = (int32_t) (0.5f * e->cfg.sample_rate + 0.5f);             // :51
+		ka.omega = 9.72f / e->cfg.sample_rate;
+		memcpy (ka.pw1, e->km_pw1, sizeof (ka.pw1));
+		ka.pw = e->km_pw.p; ka.state = e->km_state.p;
+		if (e->km_piece.reserve ((size_t) S * std::max<uint32_t> (ka.n_pieces, 1) * 4) || e->km_max.reserve ((size_t) S * std::max<uint32_t> (ka.n_pieces, 1) * 2))
+			return fail (MTR_ERR_NOMEM, "hipMalloc KMETER pieces");
+		ka.piece_state = e->km_piece.p; ka.piece_max = e->km_max.p;
+		if (mtr_launch_kmeter (ka, st)) return fail (MTR_ERR_HIP, "k_kmeter launch");
 	}
 	const bool tpb = e->cfg.meters & MTR_METER_TPBALLIST;
 	if (tpb) {

@@ -112,6 +112,25 @@ typedef struct mtr_dr14_args {
 	float*          piece_peak;   /* [S][n_pieces][2] */
 } mtr_dr14_args;
 
+/* Kmeterdsp per (stream, channel) state (jmeters/kmeterdsp.h) */
+typedef struct mtr_kmeter_state {
+	float    z1, z2, rms, peak;
+	int32_t  cnt, flag;
+} mtr_kmeter_state;
+
+typedef struct mtr_kmeter_args {
+	const float*    audio;        /* [S][stride][C] */
+	uint64_t        stride, n_groups;   /* n_frames / 4 (kmeterdsp.cc:71) */
+	uint32_t        n_streams, n_channels, n_pieces, fpp;
+	int32_t         hold;
+	float           omega, fall;
+	double          pw1[3];       /* A = [[a, 0], [c, b]] per group of four samples */
+	const double*   pw;           /* [9][3] A^(4 * 2^l), l = 0..8 (device) */
+	mtr_kmeter_state* state;      /* [S][2] */
+	double*         piece_state;  /* [S][n_pieces][4] */
+	float*          piece_max;    /* [S][n_pieces][2] */
+} mtr_kmeter_args;
+
 typedef struct mtr_tpb_args mtr_tpb_args;
 struct mtr_tpb_args {
 	const float*    audio;        /* [S][stride][C] */
@@ -144,6 +163,9 @@ int  mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uin
 int  mtr_launch_kw (int run, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kwtp (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_dr14 (const mtr_dr14_args& a, void* stream);
+int  mtr_launch_kmeter (const mtr_kmeter_args& a, void* stream);
+void mtr_kmeter_powers (float omega, double* pw /* [9][3] */, double* pw1 /* [3] */);
+uint32_t mtr_kmeter_pieces (uint64_t n_groups);
 int  mtr_fused2_upload_taps (const float* g144);
 int  mtr_fused_upload_taps (const float* g144);    /* [3][48] full 48-tap kernels of phases 1..3 */
 int  mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,

@@ -12,7 +12,7 @@ import re
 import numpy as np
 
 METER_EBU, METER_TRUEPEAK, METER_SPECTR30, METER_TPBALLIST = 0x01, 0x02, 0x04, 0x08
-METER_BITSTATS, METER_SIGDIST, METER_DR14 = 0x10, 0x20, 0x40
+METER_BITSTATS, METER_SIGDIST, METER_DR14, METER_KMETER = 0x10, 0x20, 0x40, 0x80
 BIM_LAST, DIST_BIN = 584, 361
 HIST_LEN, NBANDS = 751, 30
 
@@ -94,6 +94,8 @@ def _load():
     L.mtr_engine_intstat_reset.argtypes = [vp]
     L.mtr_engine_dr14_results.argtypes = [vp, u32, u32, vp]
     L.mtr_engine_dr14_reset.argtypes = [vp]
+    L.mtr_engine_kmeter_read.argtypes = [vp, u32, u32, vp, vp]
+    L.mtr_engine_kmeter_reset.argtypes = [vp]
     L.mtr_engine_prune_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_hist_loudness.argtypes = [vp, vp] + [C.POINTER(f32)] * 5
     L.mtr_hist_loudness.restype = None
@@ -265,6 +267,17 @@ class Engine:
         out = (Dr14Result * count)()
         _check(lib.mtr_engine_dr14_results(self._h, first, count, out), "dr14_results")
         return out
+
+    def kmeter_read(self, first=0, count=None):
+        """Kmeterdsp::read for every stream: (rms, peak) as [count, 2] arrays; arms the new-maximum flag."""
+        count = self.n_streams - first if count is None else count
+        rms = np.zeros((count, 2), np.float32)
+        peak = np.zeros((count, 2), np.float32)
+        _check(lib.mtr_engine_kmeter_read(self._h, first, count, rms.ctypes.data, peak.ctypes.data), "kmeter_read")
+        return rms, peak
+
+    def kmeter_reset(self):
+        _check(lib.mtr_engine_kmeter_reset(self._h), "kmeter_reset")
 
     def dr14_reset(self):
         _check(lib.mtr_engine_dr14_reset(self._h), "dr14_reset")
