@@ -244,6 +244,9 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	*out = nullptr;
 	if (cfg->n_streams == 0 || !(cfg->sample_rate >= 8000.f) || cfg->meters == 0) return fail (MTR_ERR_ARG, "mtr_engine_create: n_streams / sample_rate / meters");
 	if (cfg->n_channels != 1 && cfg->n_channels != 2) return fail (MTR_ERR_ARG, "n_channels must be 1 or 2");
+	if (cfg->meters & ~(uint32_t) (MTR_METER_EBU | MTR_METER_TRUEPEAK | MTR_METER_SPECTR30 | MTR_METER_TPBALLIST | MTR_METER_BITSTATS
+	                               | MTR_METER_SIGDIST | MTR_METER_DR14 | MTR_METER_KMETER))
+		return fail (MTR_ERR_ARG, "unknown bits in the meters mask");
 	if (cfg->n_channels == 1 && (cfg->meters & (MTR_METER_EBU | MTR_METER_TRUEPEAK)))
 		return fail (MTR_ERR_UNSUPPORTED, "EBU / TRUEPEAK need stereo frames (the reference's EBUr128 plugin is stereo only)");
 	if ((cfg->meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && cfg->n_channels != 1)

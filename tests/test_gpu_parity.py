@@ -219,6 +219,12 @@ def test_edge_cases(M):
         M.Engine(1, 48000.0, M.METER_EBU, n_channels=1)
     with pytest.raises(M.EngineError):
         M.Engine(0)
+    with pytest.raises(M.EngineError):
+        M.Engine(1, 48000.0, 0x100)                          # a bit that is no meter
+    with pytest.raises(M.EngineError):
+        M.Engine(1, 48000.0, M.METER_EBU, tune_layout=5)     # the matrix-pipe layout needs TRUEPEAK
+    with pytest.raises(M.EngineError):
+        M.Engine(1, 48000.0, M.METER_DR14 | M.METER_BITSTATS)   # stereo and mono-only meters do not mix
 
 
 def test_filter_bank_golden(M, oracle):
