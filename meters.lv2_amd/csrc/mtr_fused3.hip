@@ -61,8 +61,8 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 {
 	static_assert ((K & 1) == 1, "odd lane stride: conflict-free LDS accesses");
 	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-	// [W left][W right][f32 tile buffer]: reads past the end of a word array (outputs that are masked anyway)
-	// land in the next region, never outside the allocation
+	// [W left][W right][f32 tile buffer] (INPLACE: the tile lies over the two word arrays).  Operand reads of
+	// columns past the end of a short tile — masked outputs — are clamped into their array (mfir::fetch_b)
 	const int wn = (int) a.mfma_words;                                   // words per channel, a multiple of 4
 	uint32_t* const WL = reinterpret_cast<uint32_t*> (smem);
 	uint32_t* const WR = WL + wn;
@@ -265,15 +265,16 @@ __global__ __launch_bounds__ (64) void k_kwtp (const mtr_fused_args a)
 			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");            // the words of every lane are in LDS
 			const int fo = 8 * (lane & 31) + 4 * (lane >> 5);              // + (r & 3): output frame of register r in its tile
 			mfir::BFrag bl, br;
-			mfir::fetch_b (bl, WL, 0, lane);
-			mfir::fetch_b (br, WR, 0, lane);
+			const int last = (wn - 52) & ~3;                                 // 6 steps of 8 words + 4 behind a fragment's start
+			mfir::fetch_b (bl, WL, 0, lane, last);
+			mfir::fetch_b (br, WR, 0, lane, last);
 			int b0 = 0;
 			for (; b0 + 256 <= len; b0 += 256) {
 				// the next block's operands are fetched under this block's products (past the last block the
 				// read is harmless: finite words inside the allocation)
 				mfir::BFrag nl, nr;
-				mfir::fetch_b (nl, WL, b0 + 256, lane);
-				mfir::fetch_b (nr, WR, b0 + 256, lane);
+				mfir::fetch_b (nl, WL, b0 + 256, lane, last);
+				mfir::fetch_b (nr, WR, b0 + 256, lane, last);
 				mfir::f16x yl, yr;
 				mfir::tile2 (A, bl, br, yl, yr);
 #pragma unroll

@@ -130,9 +130,12 @@ __device__ __forceinline__ f16x tile (const AFrag& A, const uint32_t* W, int bas
 // The operands of one tile (7 x 16 bytes per lane) and the product for both channels with the two
 // accumulator chains interleaved (a dependent MFMA waits for its predecessor; two chains keep the pipe busy).
 struct BFrag { uint4 w[MTR_MFMA_STEPS]; };
-__device__ __forceinline__ void fetch_b (BFrag& B, const uint32_t* W, int base, int lane)
+// `last` = the highest word index a fragment may start at (array words - 52): columns past the end of a short
+// tile are masked by the caller, what they read only has to lie inside the array
+__device__ __forceinline__ void fetch_b (BFrag& B, const uint32_t* W, int base, int lane, int last)
 {
-	const uint4* const p = reinterpret_cast<const uint4*> (W + base + 8 * (lane & 31) + 4 * (lane >> 5));
+	const int o = base + 8 * (lane & 31) + 4 * (lane >> 5);
+	const uint4* const p = reinterpret_cast<const uint4*> (W + (o < last ? o : last));
 #pragma unroll
 	for (int j = 0; j < MTR_MFMA_STEPS; ++j) B.w[j] = p[2 * j];
 }
