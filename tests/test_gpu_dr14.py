@@ -102,3 +102,25 @@ def test_dr14_batch_beside_the_other_meters(M, oracle):
         assert got[s].block_count == want.block_count and want.block_count >= 3 * 2
         for c in range(2):
             assert abs(got[s].m_rms[c] - want.m_rms[c]) <= 0.02 or (got[s].m_rms[c] == want.m_rms[c])
+
+
+def test_dr14_known_answers(M):
+    """Hand-derived: the DR-14 RMS is sqrt (2 mean x^2), so a full-scale sine scores 0 dB against a peak of
+    0 dB (DR clamps at 1) and uniform noise of amplitude a scores 20 log10 sqrt (2/3) = -1.76 dB below its
+    peak; nothing is reported before the third window."""
+    fs, T = 48000.0, 48000 * 13
+    t = np.arange(T) / fs
+    sine = np.sin(2 * np.pi * 997.0 * t).astype(np.float32)
+    rng = np.random.default_rng(5)
+    noise = (0.5 * rng.uniform(-1, 1, T)).astype(np.float32)
+    x = np.stack([np.stack([sine, sine], 1), np.stack([noise, noise], 1)])
+    with M.Engine(2, fs, M.METER_DR14) as e:
+        e.process(x[:, :int(fs * 6.5)])
+        early = e.dr14()
+        assert early[0].block_count == 6 and early[0].dr[0] == 21      # two windows: not enough yet
+        e.process(x[:, int(fs * 6.5):])
+        r = e.dr14()
+    assert r[0].block_count == 12
+    assert abs(r[0].m_rms[0]) <= 0.011 and abs(r[0].m_peak[0]) <= 1e-3 and r[0].dr[0] == 1.0 and r[0].dr_total == 1.0
+    want = -20 * np.log10(np.sqrt(2.0 / 3.0))
+    assert abs(r[1].dr[0] - want) <= 0.03 and abs(r[1].dr_total - want) <= 0.03, (r[1].dr[0], want)
