@@ -83,7 +83,7 @@ struct mtr_engine {
 	DevBuf<float>              dr_peak;
 	uint64_t                   dr_scnt = 0;   // samples in the open window (all streams run in lock step)
 	DevBuf<mtr_kmeter_state>   km_state;      // [S][2]
-	DevBuf<double>             km_pw, km_piece;
+	DevBuf<double>             km_piece;
 	DevBuf<float>              km_max;
 	double                     km_pw1[3];
 	uint32_t                   km_fpp = 0;
@@ -328,7 +328,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release (); e->mfma_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
 	e->dr_state.release (); e->dr_hist.release (); e->dr_sum.release (); e->dr_peak.release ();
-	e->km_state.release (); e->km_pw.release (); e->km_piece.release (); e->km_max.release ();
+	e->km_state.release (); e->km_piece.release (); e->km_max.release ();
 	delete e;
 }
 
@@ -363,11 +363,9 @@ int mtr_engine_kmeter_reset (mtr_engine* e)
 	if (!e || !(e->cfg.meters & MTR_METER_KMETER)) return fail (MTR_ERR_ARG, "no KMETER in this engine");
 	HIPCHK (hipSetDevice (e->cfg.device));
 	const size_t n = (size_t) e->cfg.n_streams * 2;
-	if (e->km_state.reserve (n) || e->km_pw.reserve (27)) return fail (MTR_ERR_NOMEM, "hipMalloc KMETER state");
-	double pw[27];
-	mtr_kmeter_powers (9.72f / e->cfg.sample_rate, pw, e->km_pw1);       // kmeterdsp.cc:52
+	if (e->km_state.reserve (n)) return fail (MTR_ERR_NOMEM, "hipMalloc KMETER state");
+	mtr_kmeter_powers (9.72f / e->cfg.sample_rate, e->km_pw1);           // kmeterdsp.cc:52
 	HIPCHK (hipStreamSynchronize (e->last_stream));
-	HIPCHK (hipMemcpy (e->km_pw.p, pw, sizeof (pw), hipMemcpyHostToDevice));
 	HIPCHK (hipMemset (e->km_state.p, 0, n * sizeof (mtr_kmeter_state)));   // :142-146
 	return MTR_OK;
 }
@@ -703,7 +701,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ka.hold = (int32_t) (0.5f * e->cfg.sample_rate + 0.5f);             // :51
 		ka.omega = 9.72f / e->cfg.sample_rate;
 		memcpy (ka.pw1, e->km_pw1, sizeof (ka.pw1));
-		ka.pw = e->km_pw.p; ka.state = e->km_state.p;
+		ka.state = e->km_state.p;
 		if (e->km_piece.reserve ((size_t) S * std::max<uint32_t> (ka.n_pieces, 1) * 4) || e->km_max.reserve ((size_t) S * std::max<uint32_t> (ka.n_pieces, 1) * 2))
 			return fail (MTR_ERR_NOMEM, "hipMalloc KMETER pieces");
 		ka.piece_state = e->km_piece.p; ka.piece_max = e->km_max.p;

@@ -125,9 +125,8 @@ typedef struct mtr_kmeter_args {
 	int32_t         hold;
 	float           omega, fall;
 	double          pw1[3];       /* A = [[a, 0], [c, b]] per group of four samples */
-	const double*   pw;           /* [9][3] A^(4 * 2^l), l = 0..8 (device) */
 	mtr_kmeter_state* state;      /* [S][2] */
-	double*         piece_state;  /* [S][n_pieces][4] */
+	double*         piece_state;  /* [S][n_pieces][4]: each chunk's weighted sums (z1, z2 per channel), already carried to the call's end */
 	float*          piece_max;    /* [S][n_pieces][2] */
 } mtr_kmeter_args;
 
@@ -164,7 +163,7 @@ int  mtr_launch_kw (int run, const mtr_fused_args& a, uint32_t n_units, void* st
 int  mtr_launch_kwtp (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_dr14 (const mtr_dr14_args& a, void* stream);
 int  mtr_launch_kmeter (const mtr_kmeter_args& a, void* stream);
-void mtr_kmeter_powers (float omega, double* pw /* [9][3] */, double* pw1 /* [3] */);
+void mtr_kmeter_powers (float omega, double* pw1 /* [3] */);
 uint32_t mtr_kmeter_pieces (uint64_t n_groups);
 int  mtr_fused2_upload_taps (const float* g144);
 int  mtr_fused_upload_taps (const float* g144);    /* [3][48] full 48-tap kernels of phases 1..3 */
