@@ -61,14 +61,19 @@ typedef struct {
 	float    sample_rate;    /* Hz; reference: instantiate()'s `rate` (src/meters.cc:194) */
 	int32_t  device;         /* HIP device ordinal */
 	uint32_t max_frames;     /* largest n_frames a process call will carry (scratch sizing); 0 = grow on demand */
-	uint32_t tune_run;       /* frames per lane run of the fused kernel: 0 = auto, else 13, 39 (19: layouts 4 and 5 only) */
+	uint32_t tune_run;       /* frames per lane run of the fused kernel: 0 = auto, else 13, 39 (19: layouts 4 and 5 only; 38: layout 6 only) */
 	uint32_t tune_segments;  /* time segments per stream per call: 0 = auto */
 	uint32_t tune_layout;    /* 0 = auto, 1 = one wave per stream segment, 2 = wave-specialised workgroups (run 39),
-	                          * 3 = as 2 with the loader / K-filter role rotating over the four waves (auto for EBU + TP),
+	                          * 3 = as 2 with the loader / K-filter role rotating over the four waves: the exact-f32 VALU
+	                          *     interpolator, bit-for-bit an fmaf chain over the reference's taps (round 1's default),
 	                          * 4 = the K-weighting-only kernel (EBU without TRUEPEAK; auto for that mask),
 	                          * 5 = OPT-IN: layout 4 plus the interpolator on the matrix pipe (f16-split samples, f16 taps,
 	                          *     f32 accumulation; needs TRUEPEAK, run 19 or 39).  True peaks within 0.0056 dB of the
-	                          *     f32 interpolator of layouts 1-3 — inside the +-0.01 dB tolerance, not bit-identical */
+	                          *     f32 interpolator of layouts 1-3 — inside the +-0.01 dB tolerance, not bit-identical,
+	                          * 6 = layout 4 plus the interpolator on the matrix pipe AT F32 GRADE (auto wherever TRUEPEAK is
+	                          *     asked for; run 38): samples and taps as two f16 halves each, three partial products, f32
+	                          *     accumulation — within 3e-7 relative of a float64 interpolator, like the f32 chain itself;
+	                          *     held to the same 2e-6 relative parity bound as layouts 1-3 (tests/test_gpu_layout6.py) */
 	uint32_t tune_fir;       /* interpolator form: 0 = auto (mirror-symmetric), 1 = dense 3 x 48 taps;
 	                          * layout 5 only: 3 = separate f32 tile buffer (first form, one wave per SIMD) */
 	uint32_t tune_prune;     /* 1 = exact true-peak pruning (branch and bound on L1 * max|x|): identical result,
@@ -198,6 +203,8 @@ int  mtr_engine_timing_enable (mtr_engine* e, int on);
 int  mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, float* ms_bank, uint32_t* calls);
 /* With tune_prune: interpolator tile passes considered / skipped since the engine was created. */
 int  mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped);
+/* The kernel layout the engine resolved to (tune_layout = 0 picks one from the meters mask), 1..6. */
+int  mtr_engine_layout (const mtr_engine* e);
 /* K-weighting coefficients a0 a1 a2 b1 b2 c3 c4 at `sample_rate` (Ebu_r128_proc::detect_init,
  * ebumeter/ebu_r128_proc.cc:263-293) */
 int  mtr_kweight_coef (float sample_rate, float* out7);

@@ -16,6 +16,7 @@
 
 #include "mtr_internal.h"
 #include "mtr_mfma_fir.h"
+#include "mtr_mfma16_fir.h"
 
 static thread_local std::string g_err;
 
@@ -91,6 +92,7 @@ struct mtr_engine {
 	DevBuf<float>    fir_g;         // [3][48] taps in device memory
 	DevBuf<float>    fir_pmq;       // [3][24] the same in mirror-symmetric form (ballistics kernel)
 	DevBuf<uint16_t> mfma_a;        // layout 5: A fragments of the MFMA interpolator (mtr_mfma_fir.h)
+	DevBuf<uint16_t> m16_a;         // layout 6: hi / lo A fragments of the f32-grade MFMA interpolator (mtr_mfma16_fir.h)
 	DevBuf<uint32_t> prune_cnt;     // [2] interpolator tile passes considered / skipped
 	uint64_t         prune_tot[2] = { 0, 0 };
 	float            tpb_w[4];      // w1 w2 w3 g of TruePeakdsp::init
@@ -183,6 +185,10 @@ static int upload_consts (mtr_engine* e)
 		mtr_mfma_build_a (&g[0][0], af.data ());
 		if (e->mfma_a.reserve (af.size ())) return fail (MTR_ERR_NOMEM, "hipMalloc mfma_a");
 		HIPCHK (hipMemcpy (e->mfma_a.p, af.data (), af.size () * sizeof (uint16_t), hipMemcpyHostToDevice));
+		std::vector<uint16_t> a16 (MTR_M16_A_HALVES);
+		mtr_m16_build_a (&g[0][0], a16.data ());
+		if (e->m16_a.reserve (a16.size ())) return fail (MTR_ERR_NOMEM, "hipMalloc m16_a");
+		HIPCHK (hipMemcpy (e->m16_a.p, a16.data (), a16.size () * sizeof (uint16_t), hipMemcpyHostToDevice));
 	}
 	// TruePeakdsp::init, jmeters/truepeakdsp.cc:154-157 — float / float / double, stored as float
 	const float fs = e->cfg.sample_rate;
@@ -251,7 +257,7 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 		return fail (MTR_ERR_UNSUPPORTED, "EBU / TRUEPEAK need stereo frames (the reference's EBUr128 plugin is stereo only)");
 	if ((cfg->meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && cfg->n_channels != 1)
 		return fail (MTR_ERR_UNSUPPORTED, "BITSTATS / SIGDIST take mono streams (the reference's bitmeter / SigDistHist are mono plugins)");
-	if (cfg->tune_run != 0 && cfg->tune_run != 13 && cfg->tune_run != 19 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 13, 19 or 39");
+	if (cfg->tune_run != 0 && cfg->tune_run != 13 && cfg->tune_run != 19 && cfg->tune_run != 38 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 13, 19, 38 or 39");
 
 	int ndev = 0;
 	if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0)
@@ -267,9 +273,14 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	// (auto = 3: roles rotate over the four waves; measured 1.7 % faster than fixed roles, profiles/r01d)
 	// layout 4 = k_kw, the K-weighting-only kernel (mtr_kw.hip): the default when no true peak is asked for
 	const bool kw_only = (cfg->meters & MTR_METER_EBU) && !(cfg->meters & MTR_METER_TRUEPEAK);
-	e->layout = cfg->tune_layout ? (int) cfg->tune_layout : (cfg->tune_run == 13 ? 1 : (kw_only ? 4 : 3));
-	e->run = cfg->tune_run ? (int) cfg->tune_run : 39;
-	if (e->layout > 5) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..5"); }
+	// layout 6 = k_kwtp16 (mtr_fused4.hip): wherever a true peak is asked for — the interpolator on the matrix pipe at f32 grade
+	const bool has_tp = cfg->meters & MTR_METER_TRUEPEAK;
+	e->layout = cfg->tune_layout ? (int) cfg->tune_layout
+	          : cfg->tune_run == 13 ? 1 : kw_only ? 4 : (has_tp && (cfg->tune_run == 0 || cfg->tune_run == 38)) ? 6 : 3;
+	e->run = cfg->tune_run ? (int) cfg->tune_run : (e->layout == 6 ? 38 : 39);
+	if (e->layout > 6) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..6"); }
+	if ((e->layout == 6) != (e->run == 38)) { delete e; return fail (MTR_ERR_ARG, "layout 6 runs 38-frame lane runs, and only layout 6 does"); }
+	if (e->layout == 6 && !(cfg->meters & MTR_METER_TRUEPEAK)) { delete e; return fail (MTR_ERR_ARG, "layout 6 is a true-peak kernel: needs TRUEPEAK"); }
 	if (e->layout == 5 && (!(cfg->meters & MTR_METER_TRUEPEAK) || e->run == 13)) { delete e; return fail (MTR_ERR_ARG, "layout 5 is the MFMA true-peak kernel: needs TRUEPEAK and tune_run 19 or 39"); }
 	if (e->layout == 4 && !kw_only) { delete e; return fail (MTR_ERR_ARG, "layout 4 is the EBU-only kernel"); }
 	if ((e->layout == 2 || e->layout == 3) && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layouts 2 and 3 need tune_run 39"); }
@@ -325,7 +336,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->scan_m.release (); e->bin_power.release (); e->tile_power.release (); e->frag_power.release ();
 	e->stage.release (); e->tile_start.release (); e->seg_tile.release (); e->frag_tile.release ();
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
-	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release (); e->mfma_a.release ();
+	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release (); e->mfma_a.release (); e->m16_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
 	e->dr_state.release (); e->dr_hist.release (); e->dr_sum.release (); e->dr_peak.release ();
 	e->km_state.release (); e->km_piece.release (); e->km_max.release ();
@@ -630,12 +641,13 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.gain_l = 1.0f; fa.gain_r = 1.0f;                  // _chan_gain[0..1], ebu_r128_proc.cc:29
 		fa.n_frames = n_frames;
 		fa.buf_slots = e->layout >= 4 ? pl.kw_slots : pl.buf_slots;
-		fa.mfma_a = e->mfma_a.p; fa.mfma_words = pl.mfma_words;
+		fa.mfma_a = e->layout == 6 ? e->m16_a.p : e->mfma_a.p; fa.mfma_words = pl.mfma_words;
 		fa.fir_form = e->cfg.tune_fir;
 		fa.rotate = e->layout == 3;
 		fa.prune = e->cfg.tune_prune ? 1 : 0;
 		fa.prune_stats = e->prune_cnt.p;
-		const int lrc = e->layout == 5 ? mtr_launch_kwtp (e->run, ebu, fa, S * pl.n_segs, st)
+		const int lrc = e->layout == 6 ? mtr_launch_kwtp16 (e->run, ebu, fa, S * pl.n_segs, st)
+		              : e->layout == 5 ? mtr_launch_kwtp (e->run, ebu, fa, S * pl.n_segs, st)
 		              : e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
 		              : e->layout >= 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
 		                               : mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st);
@@ -875,6 +887,8 @@ int mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, v
 		return fail (MTR_ERR_HIP, "k_aggregate launch");
 	return MTR_OK;
 }
+
+int mtr_engine_layout (const mtr_engine* e) { return e ? e->layout : MTR_ERR_ARG; }
 
 int mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped)
 {

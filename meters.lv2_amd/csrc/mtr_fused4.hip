@@ -1,0 +1,367 @@
+// mtr_fused4.hip — K-weighting + true peak, the interpolator on the matrix pipe at f32 grade (gfx950), layout 6.
+//
+// Replaces, for a whole batch, Ebu_r128_proc::detect_process (ebumeter/ebu_r128_proc.cc:302-337) and
+// Resampler::process + TruePeakdsp::process_max (zita-resampler/resampler.cc:211-235,
+// jmeters/truepeakdsp.cc:101-124).  The 4x interpolator is 144 MACs per channel-sample against 4 bytes: a dense
+// contraction, and what bounds the exact-f32 VALU kernel (mtr_fused2.hip) at 17 % of the HBM roofline.  Here it runs
+// on v_mfma_f32_16x16x32_f16 with samples AND taps split into two f16 halves and three of the four partial
+// products kept (mtr_mfma16_fir.h): 2^-23-relative factors, f32 accumulation — as accurate as the f32 fmaf chain
+// (measured against a float64 interpolator: 0.8e-7 of the peak vs the chain's 3e-7), held by the parity tests to
+// the same 2e-6 relative bound as the VALU interpolator.
+//
+// One wave per (stream, time segment), workgroup = one wave, no barrier.  Per tile (one 50 ms fragment, <= 64 K frames):
+//   1. the tile has landed in LDS as f32 (LDS-DMA) behind the 48 frames before it; each lane reads its run of
+//      K frames (K even: runs start on even frames, 16-byte reads) and lanes 0..23 the last 48 frames (next halo);
+//   2. per channel: max |x| over halo and tile -> a power-of-two scale that puts it in [2^14, 2^15): the f16 halves
+//      then carry 22+ bits at any level, from denormal streams to +/-3e38; an Inf / NaN sample poisons only the
+//      outputs it reaches, and the VALU keeps max |x| (phase 0) exact;
+//   3. the run is written back IN PLACE as f16 hi / lo pair words (four arrays: the tile's f32 image is dead);
+//   4. K-filter on the unscaled registers: pass 1 -> DPP scan -> pass 2 (as k_kw: loudness is the same arithmetic);
+//   5. ceil(len / 256) blocks x 2 channels x 18 MFMAs, |max| of the twelve accumulators, last block masked;
+//   6. the halo goes back to LDS as f32, the next tile's DMA is issued over the spent words.
+// Two waves per SIMD (20 KB of LDS each): one computes while the other waits for its tile.
+#include <hip/hip_runtime.h>
+
+#include "mtr_internal.h"
+#include "mtr_mfma16_fir.h"
+#include "mtr_wave.h"
+
+namespace {
+
+__device__ __forceinline__ v2f scrub (v2f v) { return v2f{isfinite (v.x) ? v.x : 0.f, isfinite (v.y) ? v.y : 0.f}; }
+
+#define KW_STEP(p, y)                                   \
+	{                                                   \
+		v2f t_ = (p) + 1e-15f;                          \
+		t_ = t_ - b2 * z2;                              \
+		const v2f x_ = t_ - b1 * z1;                    \
+		v2f u_ = a1 * z1;                               \
+		u_ = u_ + a2 * z2;                              \
+		u_ = u_ - c4 * z4;                              \
+		u_ = u_ - c3 * z3;                              \
+		y = a0 * x_ + u_;                               \
+		z2 = z1; z1 = x_; z4 += z3; z3 += y;            \
+	}
+
+constexpr int HALO = MTR_M16_HALO;       // 48
+
+// max (m, |a|, |b|) — one v_max3_f32 with source modifiers; NaN operands lose
+__device__ __forceinline__ float max3abs (float m, float a, float b) { return fmaxf (fmaxf (m, fabsf (a)), fabsf (b)); }
+
+// power-of-two scale that puts a non-negative finite-or-inf `tm` into [2^14, 2^15), and 2^-15 / scale
+__device__ __forceinline__ void pow2_scale (float tm, float& scale, float& unscale)
+{
+	const int e = (int) ((__float_as_uint (tm) >> 23) & 0xffu);
+	const int se = min (238, 268 - e);                   // exponent field of the scale: 127 + 14 - (e - 127), clamped for tm < 2^-97
+	scale = __uint_as_float ((uint32_t) se << 23);
+	unscale = __uint_as_float ((uint32_t) (239 - se) << 23);      // 2^-(se - 127) * 2^-15
+}
+
+template <int K, bool EBU>
+__global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
+{
+	static_assert ((K & 1) == 0, "even runs: sample pairs never straddle two lanes");
+	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+	constexpr int WN = (HALO + 64 * K) / 2;                            // words per array: positions 0 .. HALO + 64 K - 1
+	static_assert (WN % 4 == 0, "arrays start on 16 bytes");
+	constexpr int CMAX = (HALO + 64 * K) / 16 - 4;                      // last column whose 64-sample window lies inside the arrays
+	uint32_t* const HL = reinterpret_cast<uint32_t*> (smem);
+	uint32_t* const HR = HL + WN;
+	uint32_t* const LL = HL + 2 * WN;
+	uint32_t* const LR = HL + 3 * WN;
+	v2f* const buf = reinterpret_cast<v2f*> (smem);                    // f32 view: slot off + i <-> position i (frame t0 - 48 + i)
+	const int lane = threadIdx.x;
+
+	const uint32_t unit = blockIdx.x;
+	const uint32_t s = unit / a.n_segs;
+	const uint32_t q = unit - s * a.n_segs;
+	const v2f* const src = reinterpret_cast<const v2f*> (a.audio) + (size_t) s * a.stride;
+	mtr_stream_state* const st = a.state + s;
+	const bool src_even = ((((size_t) s * a.stride) & 1) == 0) && ((reinterpret_cast<size_t> (a.audio) & 15) == 0);
+	v2f a0 = a.a0, a1 = a.a1, a2 = a.a2, b1 = a.b1, b2 = a.b2, c3 = a.c3, c4 = a.c4;
+	asm volatile ("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b1), "+v"(b2), "+v"(c3), "+v"(c4));
+
+	const uint32_t jt0 = a.seg_tile[q], jt1 = a.seg_tile[q + 1];
+	const int64_t seg_start = a.tile_start[jt0];
+	const int nwarm = (q > 0) ? (int) a.warm_tiles : 0;
+	const int ntile = (int) (jt1 - jt0);
+	constexpr int LT = 64 * K;
+	const int64_t id_end = (int64_t) a.n_frames - 24;                  // phase 0 of this call ends with frame n_frames - 25
+
+	auto tile_of = [&] (int jj, int64_t& t0, int& len) {
+		if (jj < 0) { t0 = seg_start + (int64_t) jj * LT; len = LT; }
+		else        { t0 = a.tile_start[jt0 + jj]; len = (int) (a.tile_start[jt0 + jj + 1] - (uint32_t) t0); }
+	};
+	// Frames [t0 - off, t0 + len) -> slots [HALO, HALO + off + len), off = t0 & 1: the DMA source stays 16-byte aligned.
+	// Then zeros behind the tile up to the end of the last lane's run: nothing below needs a per-frame length test.
+	auto stage = [&] (int jj) {
+		int64_t t0; int len;
+		tile_of (jj, t0, len);
+		const int off = (int) (t0 & 1);
+		const int nslot = len + off;
+		const bool tail_odd = (t0 + len == (int64_t) a.n_frames) && (a.n_frames & 1);
+		if (src_even && !tail_odd) {
+			const v2f* const p = src + (t0 - off) + 2 * lane;
+			for (int i = 0; i < nslot; i += 128) {
+				if (i + 2 * lane < nslot)
+				__builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void*) (p + i),
+				                                  (__attribute__ ((address_space (3))) void*) (buf + HALO + i), 16, 0, 0);
+			}
+		} else {
+			for (int i = lane; i < nslot; i += 64) buf[HALO + i] = src[t0 - off + i];
+		}
+		// (an odd nslot leaves slot HALO + nslot to the last 16-byte DMA piece: that one is cleared once the tile has landed)
+		for (int i = HALO + ((nslot + 1) & ~1) + lane; i < HALO + off + LT; i += 64) buf[i] = v2f{0.f, 0.f};
+	};
+
+	v2f k1 = 0, k2 = 0, k3 = 0, k4 = 0;            // carried K-filter state, wave-uniform
+	if (EBU && q == 0) {
+		k1 = v2f{st->kz[0], st->kz[1]}; k2 = v2f{st->kz[2], st->kz[3]};
+		k3 = v2f{st->kz[4], st->kz[5]}; k4 = v2f{st->kz[6], st->kz[7]};
+	}
+	typedef const __attribute__ ((address_space (4))) float* cfloat_p;
+	const cfloat_p CM = (cfloat_p) a.scan_m;
+	const cfloat_p F = CM + 96;
+	const v2f e1 = F[4 * K + 0], e2 = F[4 * K + 1], e3 = F[4 * K + 2], e4 = F[4 * K + 3];
+
+	m16::AFrag A;
+	A.load (a.mfma_a, lane);
+	float run_l = 0.f, run_r = 0.f;                                    // the segment's peaks so far, wave-uniform
+	uint32_t n_done = 0, n_skip = 0;
+
+	// halo of the first tile: the 47 frames before the call behind one zero (segment 0); later segments start with
+	// warm-up tiles, whose own halo is never multiplied.  Lane i < 24 holds positions 2 i and 2 i + 1.
+	v2f h0 = v2f{0.f, 0.f}, h1 = v2f{0.f, 0.f};
+	if (q == 0 && lane < HALO / 2) {
+		const v2f* const h = reinterpret_cast<const v2f*> (a.hist) + (size_t) s * MTR_FIR_HALO;
+		if (lane > 0) h0 = h[2 * lane - 1];
+		h1 = h[2 * lane];
+	}
+	{
+		int64_t t0; int len;
+		tile_of (-nwarm, t0, len);
+		const int off = (int) (t0 & 1);
+		if (lane < HALO / 2) { buf[off + 2 * lane] = h0; buf[off + 2 * lane + 1] = h1; }
+	}
+	stage (-nwarm);
+	const int wrun = HALO / 2 + (K / 2) * lane;                        // first word of this lane's run in each array
+	const int col8 = 8 * (lane & 15), kg4 = 4 * (lane >> 4);
+
+	for (int jj = -nwarm; jj < ntile; ++jj) {
+		int64_t t0; int len;
+		tile_of (jj, t0, len);
+		const int off = (int) (t0 & 1);
+
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed
+		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+		if (((len + off) & 1) && lane == 0) buf[HALO + off + len] = v2f{0.f, 0.f};
+		// the per-lane matrices of the scan's row-broadcast steps: 24 registers, fetched per tile (L1 / L2 hits that
+		// land under the split) rather than held across the products
+		mtrw::RowMats rm;
+		if (EBU) rm.load (a.scan_m + 96 + 4 * K + 4, lane);
+
+		v2f x[K];
+		if (off == 0) {
+			const float4* const p4 = reinterpret_cast<const float4*> (buf + HALO + K * lane);
+#pragma unroll
+			for (int i = 0; i < K / 2; ++i) { const float4 v = p4[i]; x[2 * i] = v2f{v.x, v.y}; x[2 * i + 1] = v2f{v.z, v.w}; }
+		} else {
+			const v2f* const xr = buf + HALO + 1 + K * lane;
+#pragma unroll
+			for (int n = 0; n < K; ++n) x[n] = xr[n];
+		}
+		// this tile's halo (positions 0..47) is in h0 / h1; the next one's = the last 48 positions of halo ++ tile
+		const v2f ph0 = h0, ph1 = h1;
+		if (lane < HALO / 2) { h0 = buf[off + len + 2 * lane]; h1 = buf[off + len + 2 * lane + 1]; }
+		asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");    // every read has returned: the f32 image is dead
+
+		// per-lane max |x| per channel
+		float ml = 0.f, mr = 0.f;
+#pragma unroll
+		for (int n = 0; n < K; n += 2) { ml = max3abs (ml, x[n].x, x[n + 1].x); mr = max3abs (mr, x[n].y, x[n + 1].y); }
+		float hl = 0.f, hr = 0.f;
+		if (lane < HALO / 2) { hl = fmaxf (fabsf (ph0.x), fabsf (ph1.x)); hr = fmaxf (fabsf (ph0.y), fabsf (ph1.y)); }
+		const float tml = mtrw::max63 (fmaxf (ml, hl)), tmr = mtrw::max63 (fmaxf (mr, hr));   // window maxima, wave-uniform
+
+		// Phase 0 (|x[n - 24]|) of this call covers frames [-24, n_frames - 24): every frame of the tile unless the call
+		// ends within 24 frames of it; the 24 frames before the call's first tile come from the history.
+		if (jj >= 0) {
+			float il = ml, ir = mr;
+			if (t0 + len > id_end) {
+				il = 0.f; ir = 0.f;
+				const int64_t lim = id_end - t0 - (int64_t) K * lane;          // frames of this lane's run inside the range
+#pragma unroll
+				for (int n = 0; n < K; ++n) if (n < lim) { il = fmaxf (il, fabsf (x[n].x)); ir = fmaxf (ir, fabsf (x[n].y)); }
+			}
+			if (q == 0 && jj == 0 && lane >= HALO / 4 && lane < HALO / 2) {
+				// positions 24..47 <-> frames -24..-1; position p counts while frame p - 48 < n_frames - 24
+				const int64_t plim = (int64_t) a.n_frames + 24;
+				if (2 * lane < plim)     { il = fmaxf (il, fabsf (ph0.x)); ir = fmaxf (ir, fabsf (ph0.y)); }
+				if (2 * lane + 1 < plim) { il = fmaxf (il, fabsf (ph1.x)); ir = fmaxf (ir, fabsf (ph1.y)); }
+			}
+			run_l = fmaxf (run_l, mtrw::max63 (il));
+			run_r = fmaxf (run_r, mtrw::max63 (ir));
+		}
+
+		// Exact peak pruning (a.prune): |y| <= L1 * max |x| over the window, 2.5684 = the largest L1 norm of the taps;
+		// a channel whose bound cannot beat its peak so far needs no products (the result is unchanged bit for bit).
+		bool need_l = jj >= 0, need_r = jj >= 0;
+		if (a.prune && jj >= 0) {
+			need_l = 2.5684f * 1.002f * tml > run_l;
+			need_r = 2.5684f * 1.002f * tmr > run_r;
+			n_done += 1; n_skip += !(need_l || need_r);
+		}
+
+		float sc_l, sc_r, un_l, un_r;
+		pow2_scale (tml, sc_l, un_l);
+		pow2_scale (tmr, sc_r, un_r);
+		if (need_l || need_r) {
+			// the run as f16 hi / lo pair words behind the halo, scaled
+			const v2f sc = v2f{sc_l, sc_r};
+			uint32_t* const w = HL + wrun;
+#pragma unroll
+			for (int i = 0; i < K / 2; ++i) {
+				const v2f u = x[2 * i] * sc, v = x[2 * i + 1] * sc;
+				uint32_t hi, lo;
+				m16::split_pair (u.x, v.x, hi, lo);
+				w[i] = hi; w[2 * WN + i] = lo;
+				m16::split_pair (u.y, v.y, hi, lo);
+				w[WN + i] = hi; w[3 * WN + i] = lo;
+			}
+			if (lane < HALO / 2) {
+				const v2f u = ph0 * sc, v = ph1 * sc;
+				uint32_t hi, lo;
+				m16::split_pair (u.x, v.x, hi, lo);
+				HL[lane] = hi; LL[lane] = lo;
+				m16::split_pair (u.y, v.y, hi, lo);
+				HR[lane] = hi; LR[lane] = lo;
+			}
+		}
+
+		if (EBU) {
+			v2f z1 = e1, z2 = e2, z3 = e3, z4 = e4;
+#pragma unroll
+			for (int n = 0; n < K; ++n) {
+				z1 += F[4 * n + 0] * x[n]; z2 += F[4 * n + 1] * x[n]; z3 += F[4 * n + 2] * x[n]; z4 += F[4 * n + 3] * x[n];
+			}
+			const int rl = min (max (len - K * lane, 0), K);
+			if (rl != K) { z1 = 0; z2 = 0; z3 = 0; z4 = 0; }
+			if (lane == 0) {
+				const cfloat_p M = CM;
+				z1 += M[0] * k1 + M[1] * k2;
+				z2 += M[4] * k1 + M[5] * k2;
+				z3 += M[8] * k1 + M[9] * k2 + M[10] * k3 + M[11] * k4;
+				z4 += M[12] * k1 + M[13] * k2 + M[14] * k3 + M[15] * k4;
+			}
+			mtrw::scan (z1, z2, z3, z4, CM, rm);
+			if (jj < 0) {
+				k1 = mtrw::pick (z1, 63); k2 = mtrw::pick (z2, 63); k3 = mtrw::pick (z3, 63); k4 = mtrw::pick (z4, 63);
+			} else {
+				z1 = mtrw::from_left (z1); z2 = mtrw::from_left (z2); z3 = mtrw::from_left (z3); z4 = mtrw::from_left (z4);
+				if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
+				// one lane has a partial run (the tile's last active one): two loop-invariant lane masks and a scalar
+				// test per step, not a vector compare per step (as k_kw)
+				const int last_l = (len - 1) / K, rl_last = len - last_l * K;
+				const bool upto = lane <= last_l, before = lane < last_l;
+				v2f sj = 0;
+#pragma unroll
+				for (int n = 0; n < K; ++n) {
+					if (n < rl_last) { if (upto) { v2f y; KW_STEP (x[n], y); sj += y * y; } }
+					else             { if (before) { v2f y; KW_STEP (x[n], y); sj += y * y; } }
+				}
+				const float sl = mtrw::sum63 (sj.x), sr = mtrw::sum63 (sj.y);
+				if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = a.gain_l * sl + a.gain_r * sr;
+				k1 = mtrw::pick (z1, last_l); k2 = mtrw::pick (z2, last_l); k3 = mtrw::pick (z3, last_l); k4 = mtrw::pick (z4, last_l);
+			}
+			k1 = scrub (k1); k2 = scrub (k2); k3 = scrub (k3); k4 = scrub (k4);
+		}
+
+		// the interpolator: 256 output frames x 3 phases per block and channel
+		if (need_l || need_r) {
+			__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");            // the words of every lane are in LDS
+			float pl = 0.f, pr = 0.f;
+			const int nb = (len + 255) >> 8;
+			const int fo = 2 * col8 + kg4;                                   // + r: output frame of register r inside its block
+			m16::BFrag bl, br;
+			{
+				const int w = min (col8, 8 * CMAX) + kg4;
+				m16::fetch_b (bl, HL, LL, w);
+				m16::fetch_b (br, HR, LR, w);
+			}
+			for (int b = 0; b < nb; ++b) {
+				// the next block's operands are fetched under this block's products; past the last block the
+				// (clamped) read is harmless
+				m16::BFrag nl, nr;
+				const int w = min (128 * (b + 1) + col8, 8 * CMAX) + kg4;
+				m16::fetch_b (nl, HL, LL, w);
+				m16::fetch_b (nr, HR, LR, w);
+				m16::f4 yl[3], yr[3];
+				m16::block (A, bl, yl);
+				m16::block (A, br, yr);
+				const int lim = len - 256 * b - fo;                          // registers r < lim are outputs of this tile
+				if (256 * (b + 1) <= len) {
+#pragma unroll
+					for (int p = 0; p < 3; ++p) {
+						pl = max3abs (pl, yl[p][0], yl[p][1]); pl = max3abs (pl, yl[p][2], yl[p][3]);
+						pr = max3abs (pr, yr[p][0], yr[p][1]); pr = max3abs (pr, yr[p][2], yr[p][3]);
+					}
+				} else {
+#pragma unroll
+					for (int p = 0; p < 3; ++p)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							pl = fmaxf (pl, r < lim ? fabsf (yl[p][r]) : 0.f);
+							pr = fmaxf (pr, r < lim ? fabsf (yr[p][r]) : 0.f);
+						}
+				}
+				bl = nl; br = nr;
+			}
+			if (need_l) run_l = fmaxf (run_l, mtrw::max63 (pl) * un_l);
+			if (need_r) run_r = fmaxf (run_r, mtrw::max63 (pr) * un_r);
+		}
+
+		// the next tile: halo as f32 in front of it, DMA over the spent words
+		if (jj + 1 < ntile) {
+			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
+			int64_t t1; int len1;
+			tile_of (jj + 1, t1, len1);
+			const int off1 = (int) (t1 & 1);
+			if (lane < HALO / 2) { buf[off1 + 2 * lane] = h0; buf[off1 + 2 * lane + 1] = h1; }
+			stage (jj + 1);
+		}
+	}
+	if (EBU && q == a.n_segs - 1 && lane == 0) {
+		st->kz[0] = k1.x; st->kz[1] = k1.y; st->kz[2] = k2.x; st->kz[3] = k2.y;
+		st->kz[4] = k3.x; st->kz[5] = k3.y; st->kz[6] = k4.x; st->kz[7] = k4.y;
+	}
+	if (a.prune && lane == 0 && a.prune_stats) {
+		atomicAdd (&a.prune_stats[0], n_done);
+		atomicAdd (&a.prune_stats[1], n_skip);
+	}
+	if (lane == 0) {
+		atomicMax (&st->tp_call[0], __float_as_uint (run_l));
+		atomicMax (&st->tp_call[1], __float_as_uint (run_r));
+	}
+}
+
+template <int K>
+int launch_kwtp16 (bool ebu, const mtr_fused_args& a, uint32_t n_units, hipStream_t st)
+{
+	const size_t words = (size_t) 4 * ((HALO + 64 * K) / 2) * sizeof (uint32_t);
+	const size_t tile = (size_t) (HALO + 1 + 64 * K) * sizeof (v2f);
+	const size_t lds = ((words > tile ? words : tile) + 15) & ~(size_t) 15;
+	if (ebu) hipLaunchKernelGGL ((k_kwtp16<K, true>), dim3 (n_units), dim3 (64), lds, st, a);
+	else     hipLaunchKernelGGL ((k_kwtp16<K, false>), dim3 (n_units), dim3 (64), lds, st, a);
+	return hipGetLastError () == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+int mtr_launch_kwtp16 (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream)
+{
+	switch (run) {
+	case 38: return launch_kwtp16<38> (ebu, a, n_units, (hipStream_t) stream);
+	default: return -2;
+	}
+}

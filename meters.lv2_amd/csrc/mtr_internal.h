@@ -46,7 +46,8 @@ struct mtr_fused_args {
 	uint32_t        rotate;       /* wave-specialised kernel: rotate the loader / K-filter role over the four waves */
 	uint32_t        prune;        /* exact peak pruning: skip the interpolator where L1 * max|x| cannot beat the running peak */
 	uint32_t*       prune_stats;  /* [2] register-tile passes considered / skipped (device counters), may be NULL */
-	const uint16_t* mfma_a;       /* layout 5: A fragments of the MFMA interpolator, [7][64][8] halves (mtr_mfma_fir.h) */
+	const uint16_t* mfma_a;       /* layout 5: A fragments of the MFMA interpolator, [7][64][8] halves (mtr_mfma_fir.h);
+	                               * layout 6: [12][64][8] hi / lo fragments (mtr_mfma16_fir.h) */
 	uint32_t        mfma_words;   /* layout 5: LDS words per channel of the {hi, lo} sample arrays (multiple of 4) */
 	float           a0, a1, a2, b1, b2, c3, c4;
 	float           gain_l, gain_r;
@@ -161,6 +162,7 @@ int  mtr_launch_fused (int run, bool ebu, bool tp, const mtr_fused_args& a, uint
 int  mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kw (int run, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kwtp (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
+int  mtr_launch_kwtp16 (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_dr14 (const mtr_dr14_args& a, void* stream);
 int  mtr_launch_kmeter (const mtr_kmeter_args& a, void* stream);
 void mtr_kmeter_powers (float omega, double* pw1 /* [3] */);

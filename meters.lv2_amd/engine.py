@@ -97,6 +97,7 @@ def _load():
     L.mtr_engine_kmeter_read.argtypes = [vp, u32, u32, vp, vp]
     L.mtr_engine_kmeter_reset.argtypes = [vp]
     L.mtr_engine_prune_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.mtr_engine_layout.argtypes = [vp]
     L.mtr_hist_loudness.argtypes = [vp, vp] + [C.POINTER(f32)] * 5
     L.mtr_hist_loudness.restype = None
     L.mtr_engine_timing_enable.argtypes = [vp, C.c_int]
@@ -298,6 +299,9 @@ class Engine:
 
     def aggregate_device(self, hist_ptr, max_ptr, stream=0):
         _check(lib.mtr_engine_aggregate_device(self._h, hist_ptr, max_ptr, stream), "aggregate_device")
+
+    def layout(self):
+        return lib.mtr_engine_layout(self._h)
 
     def prune_stats(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -183,9 +183,26 @@ class EbuStream:
                 (e.hist_M.count, e.hist_S.count), tp)
 
 
+class TpStream:
+    """One channel through TruePeakdsp::process_max + read, call by call (the per-call peak of the LV2 glue)."""
+
+    def __init__(self, lib, fs):
+        self.lib = lib
+        self.t = MoTp()
+        lib.mo_tp_init(C.byref(self.t), fs)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        self.lib.mo_tp_process_max(C.byref(self.t), x, x.size)
+        return self.lib.mo_tp_read(C.byref(self.t))
+
+
 class Oracle(_Batch):
     def ebu_stream(self, fs=48000.0):
         return EbuStream(self.lib, fs)
+
+    def tp_stream(self, fs=48000.0):
+        return TpStream(self.lib, fs)
 
     def __init__(self):
         lib = C.CDLL(build_oracle())
