@@ -26,6 +26,16 @@
 #include "mtr_mfma16_fir.h"
 #include "mtr_wave.h"
 
+// -DMTR_F4_PROF: shader cycles per phase, summed over the tiles of one workgroup (read back with mtr_debug_f4_prof)
+#ifdef MTR_F4_PROF
+__device__ unsigned long long g_f4_prof[12];
+#define PROF_NOW(v) unsigned long long v; asm volatile ("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define PROF_ADD(i, d) pr_[i] += (d)
+#else
+#define PROF_NOW(v)
+#define PROF_ADD(i, d)
+#endif
+
 namespace {
 
 __device__ __forceinline__ v2f scrub (v2f v) { return v2f{isfinite (v.x) ? v.x : 0.f, isfinite (v.y) ? v.y : 0.f}; }
@@ -48,10 +58,11 @@ constexpr int HALO = MTR_M16_HALO;       // 48
 // max (m, |a|, |b|) — one v_max3_f32 with source modifiers; NaN operands lose
 __device__ __forceinline__ float max3abs (float m, float a, float b) { return fmaxf (fmaxf (m, fabsf (a)), fabsf (b)); }
 
-// power-of-two scale that puts a non-negative finite-or-inf `tm` into [2^14, 2^15), and 2^-15 / scale
-__device__ __forceinline__ void pow2_scale (float tm, float& scale, float& unscale)
+// power-of-two scale that puts a value with exponent field `e` (0 = zero / denormal .. 255 = Inf) into [2^14, 2^15),
+// and 2^-15 / scale
+__device__ __forceinline__ void pow2_scale (uint32_t e_, float& scale, float& unscale)
 {
-	const int e = (int) ((__float_as_uint (tm) >> 23) & 0xffu);
+	const int e = (int) e_;
 	const int se = min (238, 268 - e);                   // exponent field of the scale: 127 + 14 - (e - 127), clamped for tm < 2^-97
 	scale = __uint_as_float ((uint32_t) se << 23);
 	unscale = __uint_as_float ((uint32_t) (239 - se) << 23);      // 2^-(se - 127) * 2^-15
@@ -126,7 +137,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 
 	m16::AFrag A;
 	A.load (a.mfma_a, lane);
-	float run_l = 0.f, run_r = 0.f;                                    // the segment's peaks so far, wave-uniform
+	float pk_l = 0.f, pk_r = 0.f;                                      // the segment's peaks so far, per lane
 	uint32_t n_done = 0, n_skip = 0;
 
 	// halo of the first tile: the 47 frames before the call behind one zero (segment 0); later segments start with
@@ -147,12 +158,17 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 	const int wrun = HALO / 2 + (K / 2) * lane;                        // first word of this lane's run in each array
 	const int col8 = 8 * (lane & 15), kg4 = 4 * (lane >> 4);
 
+#ifdef MTR_F4_PROF
+	unsigned long long pr_[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
 	for (int jj = -nwarm; jj < ntile; ++jj) {
 		int64_t t0; int len;
 		tile_of (jj, t0, len);
 		const int off = (int) (t0 & 1);
 
+		PROF_NOW (c0_);
 		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed
+		PROF_NOW (c1_); PROF_ADD (0, c1_ - c0_);
 		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
 		if (((len + off) & 1) && lane == 0) buf[HALO + off + len] = v2f{0.f, 0.f};
 		// the per-lane matrices of the scan's row-broadcast steps: 24 registers, fetched per tile (L1 / L2 hits that
@@ -174,6 +190,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		const v2f ph0 = h0, ph1 = h1;
 		if (lane < HALO / 2) { h0 = buf[off + len + 2 * lane]; h1 = buf[off + len + 2 * lane + 1]; }
 		asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");    // every read has returned: the f32 image is dead
+		PROF_NOW (c2_); PROF_ADD (1, c2_ - c1_);
 
 		// per-lane max |x| per channel
 		float ml = 0.f, mr = 0.f;
@@ -181,10 +198,14 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		for (int n = 0; n < K; n += 2) { ml = max3abs (ml, x[n].x, x[n + 1].x); mr = max3abs (mr, x[n].y, x[n + 1].y); }
 		float hl = 0.f, hr = 0.f;
 		if (lane < HALO / 2) { hl = fmaxf (fabsf (ph0.x), fabsf (ph1.x)); hr = fmaxf (fabsf (ph0.y), fabsf (ph1.y)); }
-		const float tml = mtrw::max63 (fmaxf (ml, hl)), tmr = mtrw::max63 (fmaxf (mr, hr));   // window maxima, wave-uniform
+		// The scales need only the exponents of the two window maxima: both ride through ONE wave reduction as a pair
+		// of 16-bit fields (v_pk_max_u16); NaNs have lost every fmaxf above, an Inf gives exponent 255.
+		const uint32_t epair = (__float_as_uint (fmaxf (ml, hl)) >> 23) | ((__float_as_uint (fmaxf (mr, hr)) >> 23) << 16);
+		const uint32_t emax = mtrw::max63_u16x2 (epair);
 
 		// Phase 0 (|x[n - 24]|) of this call covers frames [-24, n_frames - 24): every frame of the tile unless the call
-		// ends within 24 frames of it; the 24 frames before the call's first tile come from the history.
+		// ends within 24 frames of it; the 24 frames before the call's first tile come from the history.  Peaks are
+		// kept per lane and reduced once, at the end of the segment.
 		if (jj >= 0) {
 			float il = ml, ir = mr;
 			if (t0 + len > id_end) {
@@ -199,22 +220,26 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 				if (2 * lane < plim)     { il = fmaxf (il, fabsf (ph0.x)); ir = fmaxf (ir, fabsf (ph0.y)); }
 				if (2 * lane + 1 < plim) { il = fmaxf (il, fabsf (ph1.x)); ir = fmaxf (ir, fabsf (ph1.y)); }
 			}
-			run_l = fmaxf (run_l, mtrw::max63 (il));
-			run_r = fmaxf (run_r, mtrw::max63 (ir));
+			pk_l = fmaxf (pk_l, il);
+			pk_r = fmaxf (pk_r, ir);
 		}
 
 		// Exact peak pruning (a.prune): |y| <= L1 * max |x| over the window, 2.5684 = the largest L1 norm of the taps;
 		// a channel whose bound cannot beat its peak so far needs no products (the result is unchanged bit for bit).
+		// Only this option needs the maxima and the peaks so far wave-wide, per tile.
 		bool need_l = jj >= 0, need_r = jj >= 0;
 		if (a.prune && jj >= 0) {
+			const float tml = mtrw::max63 (fmaxf (ml, hl)), tmr = mtrw::max63 (fmaxf (mr, hr));
+			const float run_l = mtrw::max63 (pk_l), run_r = mtrw::max63 (pk_r);
 			need_l = 2.5684f * 1.002f * tml > run_l;
 			need_r = 2.5684f * 1.002f * tmr > run_r;
 			n_done += 1; n_skip += !(need_l || need_r);
 		}
 
+		PROF_NOW (c3_); PROF_ADD (2, c3_ - c2_);
 		float sc_l, sc_r, un_l, un_r;
-		pow2_scale (tml, sc_l, un_l);
-		pow2_scale (tmr, sc_r, un_r);
+		pow2_scale (emax & 0xffffu, sc_l, un_l);
+		pow2_scale (emax >> 16, sc_r, un_r);
 		if (need_l || need_r) {
 			// the run as f16 hi / lo pair words behind the halo, scaled
 			const v2f sc = v2f{sc_l, sc_r};
@@ -238,6 +263,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 			}
 		}
 
+		PROF_NOW (c4_); PROF_ADD (3, c4_ - c3_);
 		if (EBU) {
 			v2f z1 = e1, z2 = e2, z3 = e3, z4 = e4;
 #pragma unroll
@@ -253,7 +279,9 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 				z3 += M[8] * k1 + M[9] * k2 + M[10] * k3 + M[11] * k4;
 				z4 += M[12] * k1 + M[13] * k2 + M[14] * k3 + M[15] * k4;
 			}
+			PROF_NOW (k1_); PROF_ADD (9, k1_ - c4_);
 			mtrw::scan (z1, z2, z3, z4, CM, rm);
+			PROF_NOW (k2_); PROF_ADD (10, k2_ - k1_);
 			if (jj < 0) {
 				k1 = mtrw::pick (z1, 63); k2 = mtrw::pick (z2, 63); k3 = mtrw::pick (z3, 63); k4 = mtrw::pick (z4, 63);
 			} else {
@@ -269,42 +297,63 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 					if (n < rl_last) { if (upto) { v2f y; KW_STEP (x[n], y); sj += y * y; } }
 					else             { if (before) { v2f y; KW_STEP (x[n], y); sj += y * y; } }
 				}
-				const float sl = mtrw::sum63 (sj.x), sr = mtrw::sum63 (sj.y);
-				if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = a.gain_l * sl + a.gain_r * sr;
+				const float pw = mtrw::sum63 (a.gain_l * sj.x + a.gain_r * sj.y);
+				if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = pw;
 				k1 = mtrw::pick (z1, last_l); k2 = mtrw::pick (z2, last_l); k3 = mtrw::pick (z3, last_l); k4 = mtrw::pick (z4, last_l);
 			}
 			k1 = scrub (k1); k2 = scrub (k2); k3 = scrub (k3); k4 = scrub (k4);
 		}
 
-		// the interpolator: 256 output frames x 3 phases per block and channel
+		PROF_NOW (c5_); PROF_ADD (4, c5_ - c4_);
+		// The interpolator: 256 output frames x 3 phases per block and channel.  Operands ping-pong between the channels:
+		// the right channel's fragments land under the left channel's 18 products and the next block's left fragments
+		// under the right channel's; each channel's |max| rides between the other channel's MFMAs (two VALU
+		// instructions per 16x16x32 MFMA are free, tools/coissue.hip).
 		if (need_l || need_r) {
 			__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
 			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");            // the words of every lane are in LDS
 			float pl = 0.f, pr = 0.f;
-			const int nb = (len + 255) >> 8;
+			const int nfull = len >> 8;                                      // blocks whose 256 outputs all belong to the tile
 			const int fo = 2 * col8 + kg4;                                   // + r: output frame of register r inside its block
 			m16::BFrag bl, br;
-			{
-				const int w = min (col8, 8 * CMAX) + kg4;
-				m16::fetch_b (bl, HL, LL, w);
-				m16::fetch_b (br, HR, LR, w);
+			m16::f4 yl[3], yr[3];
+#pragma unroll
+			for (int p = 0; p < 3; ++p) yr[p] = m16::f4{0.f, 0.f, 0.f, 0.f};
+			m16::fetch_b (bl, HL, LL, min (col8, 8 * CMAX) + kg4);
+			for (int b = 0; b < nfull; ++b) {
+				m16::fetch_b (br, HR, LR, min (128 * b + col8, 8 * CMAX) + kg4);
+				__builtin_amdgcn_sched_barrier (0);
+				m16::block (A, bl, yl);
+#pragma unroll
+				for (int p = 0; p < 3; ++p) { pr = max3abs (pr, yr[p][0], yr[p][1]); pr = max3abs (pr, yr[p][2], yr[p][3]); }   // block b - 1
+#pragma unroll
+				for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier (0x8, 3, 0); __builtin_amdgcn_sched_group_barrier (0x2, 1, 0); }
+				__builtin_amdgcn_sched_barrier (0);
+				m16::fetch_b (bl, HL, LL, min (128 * (b + 1) + col8, 8 * CMAX) + kg4);   // past the last block: a harmless clamped read
+				__builtin_amdgcn_sched_barrier (0);
+				m16::block (A, br, yr);
+#pragma unroll
+				for (int p = 0; p < 3; ++p) { pl = max3abs (pl, yl[p][0], yl[p][1]); pl = max3abs (pl, yl[p][2], yl[p][3]); }
+#pragma unroll
+				for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier (0x8, 3, 0); __builtin_amdgcn_sched_group_barrier (0x2, 1, 0); }
+				__builtin_amdgcn_sched_barrier (0);
 			}
-			for (int b = 0; b < nb; ++b) {
-				// the next block's operands are fetched under this block's products; past the last block the
-				// (clamped) read is harmless
-				m16::BFrag nl, nr;
-				const int w = min (128 * (b + 1) + col8, 8 * CMAX) + kg4;
-				m16::fetch_b (nl, HL, LL, w);
-				m16::fetch_b (nr, HR, LR, w);
-				m16::f4 yl[3], yr[3];
+#pragma unroll
+			for (int p = 0; p < 3; ++p) { pr = max3abs (pr, yr[p][0], yr[p][1]); pr = max3abs (pr, yr[p][2], yr[p][3]); }
+			if (len & 255) {
+				// the tile's last block: frames past its end belong to the next tile (or do not exist yet)
+				m16::fetch_b (br, HR, LR, min (128 * nfull + col8, 8 * CMAX) + kg4);
 				m16::block (A, bl, yl);
 				m16::block (A, br, yr);
-				const int lim = len - 256 * b - fo;                          // registers r < lim are outputs of this tile
-				if (256 * (b + 1) <= len) {
+				const int lim = len - 256 * nfull - fo;                      // registers r < lim are outputs of this tile
+				if ((len & 3) == 0) {
+					// a lane's four registers are all in or all out: one branch on the lane mask, no per-register tests
+					if (lim > 0) {
 #pragma unroll
-					for (int p = 0; p < 3; ++p) {
-						pl = max3abs (pl, yl[p][0], yl[p][1]); pl = max3abs (pl, yl[p][2], yl[p][3]);
-						pr = max3abs (pr, yr[p][0], yr[p][1]); pr = max3abs (pr, yr[p][2], yr[p][3]);
+						for (int p = 0; p < 3; ++p) {
+							pl = max3abs (pl, yl[p][0], yl[p][1]); pl = max3abs (pl, yl[p][2], yl[p][3]);
+							pr = max3abs (pr, yr[p][0], yr[p][1]); pr = max3abs (pr, yr[p][2], yr[p][3]);
+						}
 					}
 				} else {
 #pragma unroll
@@ -315,11 +364,11 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 							pr = fmaxf (pr, r < lim ? fabsf (yr[p][r]) : 0.f);
 						}
 				}
-				bl = nl; br = nr;
 			}
-			if (need_l) run_l = fmaxf (run_l, mtrw::max63 (pl) * un_l);
-			if (need_r) run_r = fmaxf (run_r, mtrw::max63 (pr) * un_r);
+			pk_l = fmaxf (pk_l, pl * un_l);                                  // back to the samples' own scale (exact)
+			pk_r = fmaxf (pk_r, pr * un_r);
 		}
+		PROF_NOW (c6_); PROF_ADD (5, c6_ - c5_);
 
 		// the next tile: halo as f32 in front of it, DMA over the spent words
 		if (jj + 1 < ntile) {
@@ -330,7 +379,11 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 			if (lane < HALO / 2) { buf[off1 + 2 * lane] = h0; buf[off1 + 2 * lane + 1] = h1; }
 			stage (jj + 1);
 		}
+		PROF_NOW (c7_); PROF_ADD (6, c7_ - c6_); PROF_ADD (7, c7_ - c0_); PROF_ADD (8, 1);
 	}
+#ifdef MTR_F4_PROF
+	if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 12; ++i) g_f4_prof[i] = pr_[i];
+#endif
 	if (EBU && q == a.n_segs - 1 && lane == 0) {
 		st->kz[0] = k1.x; st->kz[1] = k1.y; st->kz[2] = k2.x; st->kz[3] = k2.y;
 		st->kz[4] = k3.x; st->kz[5] = k3.y; st->kz[6] = k4.x; st->kz[7] = k4.y;
@@ -339,9 +392,11 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		atomicAdd (&a.prune_stats[0], n_done);
 		atomicAdd (&a.prune_stats[1], n_skip);
 	}
+	pk_l = mtrw::max63 (pk_l);
+	pk_r = mtrw::max63 (pk_r);
 	if (lane == 0) {
-		atomicMax (&st->tp_call[0], __float_as_uint (run_l));
-		atomicMax (&st->tp_call[1], __float_as_uint (run_r));
+		atomicMax (&st->tp_call[0], __float_as_uint (pk_l));
+		atomicMax (&st->tp_call[1], __float_as_uint (pk_r));
 	}
 }
 
@@ -357,6 +412,13 @@ int launch_kwtp16 (bool ebu, const mtr_fused_args& a, uint32_t n_units, hipStrea
 }
 
 }  // namespace
+
+#ifdef MTR_F4_PROF
+extern "C" int mtr_debug_f4_prof (unsigned long long* out)
+{
+	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_f4_prof), 12 * sizeof (unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int mtr_launch_kwtp16 (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream)
 {

@@ -60,6 +60,21 @@ __device__ __forceinline__ float max63 (float v)
 	return __int_as_float (__builtin_amdgcn_readlane (__float_as_int (v), 63));
 }
 
+// componentwise max of two 16-bit fields per lane over the wave (v_pk_max_u16), returned wave-uniform
+__device__ __forceinline__ uint32_t max63_u16x2 (uint32_t v)
+{
+	typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+#define MTRW_PKMAX(CTRL, MASK)                                                                                  \
+	{                                                                                                           \
+		const uint32_t o = (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, CTRL, MASK, 0xF, true);         \
+		v = __builtin_bit_cast (uint32_t, __builtin_elementwise_max (__builtin_bit_cast (us2, v), __builtin_bit_cast (us2, o))); \
+	}
+	MTRW_PKMAX (0x111, 0xF) MTRW_PKMAX (0x112, 0xF) MTRW_PKMAX (0x114, 0xF) MTRW_PKMAX (0x118, 0xF)
+	MTRW_PKMAX (0x142, 0xA) MTRW_PKMAX (0x143, 0xC)
+#undef MTRW_PKMAX
+	return (uint32_t) __builtin_amdgcn_readlane ((int) v, 63);
+}
+
 // One application of a K-weighting transition-matrix power (block lower triangular: the shelving
 // stage does not see the integrators): z += M w.
 #define MTRW_APPLY(M, w1, w2, w3, w4)                                                     \

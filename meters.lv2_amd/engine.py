@@ -17,7 +17,8 @@ BIM_LAST, DIST_BIN = 584, 361
 HIST_LEN, NBANDS = 751, 30
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(_HERE, "lib", "libmtr_engine.so")
+# MTR_LIB: an alternative build of the same library (instrumented kernels, tools/f4_prof.py); never a different backend
+lib_path = os.environ.get("MTR_LIB") or os.path.join(_HERE, "lib", "libmtr_engine.so")
 
 
 class EngineError(RuntimeError):

@@ -134,13 +134,113 @@ static void run (const char* name, int threads, int wg_per_cu, float* d_out, uns
 	fflush (stdout);
 }
 
-int main ()
+
+// ---- the real mix: per block 36 MFMAs (two channels x 18, operands from LDS) with NPK packed K-filter steps' worth of
+// dependent v_pk_fma_f32 (11 per step, as KW_STEP) and NSC scalar v_max3 spread between them
+template <int NSTEP, int NMAX, int PAT>
+__global__ void k_mix (float* out, unsigned long long* cyc, int iters, float seed)
+{
+	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	uint4* const L = reinterpret_cast<uint4*> (smem);
+	for (int i = threadIdx.x; i < 1024; i += blockDim.x) L[i] = uint4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+	__syncthreads ();
+	h8 a[6];
+	for (int i = 0; i < 6; ++i) for (int j = 0; j < 8; ++j) a[i][j] = (_Float16) (0.001f * (lane + i + j));
+	v2f z1 = {seed, seed}, z2 = z1, z3 = z1, z4 = z1, sj = {0, 0};
+	const v2f a0 = {1.f + seed, 1.f}, a1 = {-1.9f, -1.9f}, a2 = {0.9f, 0.9f}, b1 = {-1.6f, -1.6f}, b2 = {0.7f, 0.7f}, c3 = {0.01f, 0.01f}, c4 = {2e-5f, 2e-5f};
+	v2f xs[4] = {{seed + lane, 1.f}, {2.f, seed}, {3.f, 1.f}, {seed, 4.f}};
+	float pk = 0.f;
+	const uint4* const lp = L + lane;
+	unsigned long long t0 = __builtin_readcyclecounter ();
+	for (int it = 0; it < iters; ++it) {
+		uint4 b0 = lp[0], b1_ = lp[64], b2_ = lp[128], b3 = lp[192];
+		f4 y[6];
+#pragma unroll
+		for (int i = 0; i < 6; ++i) y[i] = f4{0, 0, 0, 0};
+#pragma unroll
+		for (int k = 0; k < 36; ++k) {
+			const uint4& bb = (k / 9) == 0 ? b0 : (k / 9) == 1 ? b1_ : (k / 9) == 2 ? b2_ : b3;
+			y[k % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16 (a[k % 6], __builtin_bit_cast (h8, bb), y[k % 6], 0, 0, 0);
+		}
+#pragma unroll
+		for (int sidx = 0; sidx < NSTEP; ++sidx) {
+			v2f t_ = xs[sidx & 3] + 1e-15f;
+			t_ = t_ - b2 * z2;
+			const v2f x_ = t_ - b1 * z1;
+			v2f u_ = a1 * z1;
+			u_ = u_ + a2 * z2;
+			u_ = u_ - c4 * z4;
+			u_ = u_ - c3 * z3;
+			const v2f yy = a0 * x_ + u_;
+			z2 = z1; z1 = x_; z4 += z3; z3 += yy;
+			sj += yy * yy;
+		}
+#pragma unroll
+		for (int i = 0; i < NMAX; ++i) pk = fmaxf (fmaxf (pk, fabsf (y[i % 6][(2 * i / 6) & 3])), fabsf (y[i % 6][((2 * i / 6) + 1) & 3]));
+		if (PAT == 1) {
+			// one VALU after every MFMA
+#pragma unroll
+			for (int k = 0; k < 36; ++k) { SGB (M_MFMA, 1); SGB (M_VALU, 1); }
+		} else if (PAT == 2) {
+			// all MFMAs, then all VALU
+			SGB (M_MFMA, 36);
+		}
+	}
+	unsigned long long t1 = __builtin_readcyclecounter ();
+	float r = pk + z1.x + z1.y + z2.x + z3.x + z3.y + z4.x + z4.y + sj.x + sj.y;
+	out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+	if (blockIdx.x == 0 && lane == 0) cyc[0] = t1 - t0;
+}
+
+template <int NSTEP, int NMAX, int PAT>
+static void run_mix (const char* name, int wg_per_cu, float* d_out, unsigned long long* d_cyc)
+{
+	const int iters = 400, grid = 256 * wg_per_cu;
+	const size_t lds = 160 * 1024 / wg_per_cu;
+	auto kern = k_mix<NSTEP, NMAX, PAT>;
+	hipFuncSetAttribute ((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	hipEvent_t e0, e1;
+	hipEventCreate (&e0); hipEventCreate (&e1);
+	hipLaunchKernelGGL (kern, dim3 (grid), dim3 (64), lds, 0, d_out, d_cyc, 4, 0.f);
+	hipDeviceSynchronize ();
+	hipEventRecord (e0);
+	hipLaunchKernelGGL (kern, dim3 (grid), dim3 (64), lds, 0, d_out, d_cyc, iters, 0.f);
+	hipEventRecord (e1);
+	hipEventSynchronize (e1);
+	float ms;
+	hipEventElapsedTime (&ms, e0, e1);
+	unsigned long long c = 0;
+	hipMemcpy (&c, d_cyc, sizeof (c), hipMemcpyDeviceToHost);
+	printf ("%-64s w/SIMD=%d  wall/iter/SIMD %7.1f ns  memtime/iter(w0) %8.1f\n", name, wg_per_cu / 4, ms * 1e6 / iters / (wg_per_cu / 4), (double) c / iters);
+	fflush (stdout);
+}
+
+int main (int argc, char** argv)
 {
 	float* d;
 	unsigned long long* dc;
 	hipMalloc (&d, 256 * 16 * 512 * 4);
 	hipMalloc (&dc, 64);
 	hipMemset (dc, 0, 64);
+	if (argc > 1) {
+		for (int w : {4, 8}) {
+			run_mix<0, 0, 0> ("36 mfma16 + 4 ds_read_b128", w, d, dc);
+			run_mix<0, 12, 0> ("36 mfma16 + 12 max3 (compiler order)", w, d, dc);
+			run_mix<0, 12, 1> ("36 mfma16 + 12 max3 (1 VALU after each MFMA)", w, d, dc);
+			run_mix<1, 0, 0> ("36 mfma16 + 1 K-filter step (12 pk), compiler order", w, d, dc);
+			run_mix<2, 0, 0> ("36 mfma16 + 2 K-filter steps (24 pk), compiler order", w, d, dc);
+			run_mix<2, 0, 1> ("36 mfma16 + 2 K-filter steps (24 pk), 1 VALU per MFMA", w, d, dc);
+			run_mix<3, 0, 1> ("36 mfma16 + 3 K-filter steps (36 pk), 1 VALU per MFMA", w, d, dc);
+			run_mix<3, 0, 2> ("36 mfma16 then 3 K-filter steps (36 pk) (serial)", w, d, dc);
+			run_mix<3, 12, 1> ("36 mfma16 + 3 steps (36 pk) + 12 max3, 1 VALU per MFMA", w, d, dc);
+			run_mix<4, 12, 1> ("36 mfma16 + 4 steps (48 pk) + 12 max3, 1 VALU per MFMA", w, d, dc);
+			run_mix<4, 12, 0> ("36 mfma16 + 4 steps (48 pk) + 12 max3, compiler order", w, d, dc);
+			run_mix<4, 12, 2> ("36 mfma16 then 4 steps (48 pk) + 12 max3 (serial)", w, d, dc);
+			run_mix<4, 0, 2> ("(36 mfma16 then) 4 steps (48 pk) serial", w, d, dc);
+		}
+		return 0;
+	}
 	// --- the parts alone, one wave per workgroup, 1 / 2 / 4 waves per SIMD
 	for (int w : {4, 8, 16}) {
 		run<16, 36, 0, false, 1, false> ("36 mfma16x16x32 only", 64, w, d, dc);

@@ -12,6 +12,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d $out/pmc2 --output-format csv -- $B > $out/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc3 --output-format csv -- $B > $out/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $out/pmc4 --output-format csv -- $B > $out/pmc4.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC -d $out/pmc5 --output-format csv -- $B > $out/pmc5.log 2>&1
 find $out -name "*.csv" | head -30
 python - <<PY
 import csv, glob, collections
@@ -19,7 +20,7 @@ for f in sorted(glob.glob("$out/trace/**/*kernel_stats.csv", recursive=True)):
     print("==", f)
     for i, row in enumerate(csv.reader(open(f))):
         if i < 8: print(row)
-for p in ("pmc1","pmc2","pmc3","pmc4"):
+for p in ("pmc1","pmc2","pmc3","pmc4","pmc5"):
     for f in sorted(glob.glob("$out/%s/**/*counter_collection.csv" % p, recursive=True)):
         acc = collections.defaultdict(lambda: [0.0, 0])
         rd = csv.DictReader(open(f))
@@ -28,6 +29,6 @@ for p in ("pmc1","pmc2","pmc3","pmc4"):
             acc[k][0] += float(row.get("Counter_Value", 0)); acc[k][1] += 1
         print("==", p)
         for k, (v, n) in sorted(acc.items()):
-            if any(t in k[0] for t in ("fused", "bank", "gate", "k_kw", "bitstats", "sigdist", "k_tpb")):
+            if any(t in k[0] for t in ("fused", "bank", "gate", "k_kw", "bitstats", "sigdist", "k_tpb", "kwtp")):
                 print(k, "avg/dispatch = %.4g" % (v / n), "n =", n)
 PY
