@@ -22,6 +22,8 @@
 // Two waves per SIMD (20 KB of LDS each): one computes while the other waits for its tile.
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "mtr_internal.h"
 #include "mtr_mfma16_fir.h"
 #include "mtr_wave.h"
@@ -54,6 +56,56 @@ __device__ __forceinline__ v2f scrub (v2f v) { return v2f{isfinite (v.x) ? v.x :
 	}
 
 constexpr int HALO = MTR_M16_HALO;       // 48
+
+// Two K-weighting steps (frames n, n + 1 of every lane's run) as one hand-scheduled block.  What hipcc makes of the
+// masked C++ loop (one lane per tile has a partial run) is, per step, a scalar branch, an exec save / restore, five
+// 64-bit moves for the phi nodes and a wait state between every pair of dependent packed instructions; here the
+// lane mask is picked without a branch (steps n < rl run under `upto`, the others under `before`: two SALU
+// instructions), the shelving states ping-pong between two registers (x_ of step n overwrites z2, which is z1 of
+// step n + 1), and the next step's first instructions fill the slots behind the dependent ones: 22 packed
+// instructions, 2 wait states, 5 SALU per pair.  Same operations in the same association as KW_STEP.
+// On entry zA = z1, zB = z2; a lane that ran an odd number of steps holds them swapped (the caller picks).
+template <int N>
+__device__ __forceinline__ void kw_pair (v2f x0, v2f x1, v2f& zA, v2f& zB, v2f& z3, v2f& z4, v2f& sj, v2f a0, v2f a1, v2f a2,
+                                         v2f b1, v2f b2, v2f c3, v2f c4, v2f eps, uint64_t upto, uint64_t before, int rl)
+{
+	v2f t, u, y, t2, u2;
+	asm volatile (
+		"s_cmp_gt_i32 %[rl], %[n0]\n\t"
+		"s_cselect_b64 exec, %[upto], %[before]\n\t"
+		"v_pk_add_f32 %[t], %[x0], %[eps]\n\t"
+		"v_pk_mul_f32 %[u], %[a1], %[zA]\n\t"
+		"v_pk_fma_f32 %[t], %[b2], %[zB], %[t] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+		"v_pk_fma_f32 %[u], %[a2], %[zB], %[u]\n\t"
+		"v_pk_fma_f32 %[zB], %[b1], %[zA], %[t] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+		"v_pk_fma_f32 %[u], %[c4], %[z4], %[u] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+		"v_pk_add_f32 %[z4], %[z4], %[z3]\n\t"
+		"v_pk_fma_f32 %[u], %[c3], %[z3], %[u] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+		"v_pk_add_f32 %[t2], %[x1], %[eps]\n\t"
+		"v_pk_fma_f32 %[y], %[a0], %[zB], %[u]\n\t"
+		"v_pk_mul_f32 %[u2], %[a1], %[zB]\n\t"
+		"v_pk_add_f32 %[z3], %[z3], %[y]\n\t"
+		"v_pk_fma_f32 %[sj], %[y], %[y], %[sj]\n\t"
+		"s_cmp_gt_i32 %[rl], %[n1]\n\t"
+		"s_cselect_b64 exec, %[upto], %[before]\n\t"
+		"v_pk_fma_f32 %[t2], %[b2], %[zA], %[t2] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+		"v_pk_fma_f32 %[u2], %[a2], %[zA], %[u2]\n\t"
+		"v_pk_fma_f32 %[zA], %[b1], %[zB], %[t2] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+		"v_pk_fma_f32 %[u2], %[c4], %[z4], %[u2] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+		"v_pk_add_f32 %[z4], %[z4], %[z3]\n\t"
+		"v_pk_fma_f32 %[u2], %[c3], %[z3], %[u2] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_fma_f32 %[y], %[a0], %[zA], %[u2]\n\t"
+		"s_nop 0\n\t"
+		"v_pk_add_f32 %[z3], %[z3], %[y]\n\t"
+		"v_pk_fma_f32 %[sj], %[y], %[y], %[sj]\n\t"
+		"s_mov_b64 exec, -1"
+		: [zA] "+v"(zA), [zB] "+v"(zB), [z3] "+v"(z3), [z4] "+v"(z4), [sj] "+v"(sj),
+		  [t] "=&v"(t), [u] "=&v"(u), [y] "=&v"(y), [t2] "=&v"(t2), [u2] "=&v"(u2)
+		: [x0] "v"(x0), [x1] "v"(x1), [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [b1] "v"(b1), [b2] "v"(b2), [c3] "v"(c3), [c4] "v"(c4),
+		  [eps] "v"(eps), [upto] "s"(upto), [before] "s"(before), [rl] "s"(rl), [n0] "n"(N), [n1] "n"(N + 1)
+		: "scc");
+}
 
 // max (m, |a|, |b|) — one v_max3_f32 with source modifiers; NaN operands lose
 __device__ __forceinline__ float max3abs (float m, float a, float b) { return fmaxf (fmaxf (m, fabsf (a)), fabsf (b)); }
@@ -91,6 +143,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 	const bool src_even = ((((size_t) s * a.stride) & 1) == 0) && ((reinterpret_cast<size_t> (a.audio) & 15) == 0);
 	v2f a0 = a.a0, a1 = a.a1, a2 = a.a2, b1 = a.b1, b2 = a.b2, c3 = a.c3, c4 = a.c4;
 	asm volatile ("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b1), "+v"(b2), "+v"(c3), "+v"(c4));
+	const v2f eps2 = v2f{1e-15f, 1e-15f};
 
 	const uint32_t jt0 = a.seg_tile[q], jt1 = a.seg_tile[q + 1];
 	const int64_t seg_start = a.tile_start[jt0];
@@ -287,15 +340,18 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 			} else {
 				z1 = mtrw::from_left (z1); z2 = mtrw::from_left (z2); z3 = mtrw::from_left (z3); z4 = mtrw::from_left (z4);
 				if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
-				// one lane has a partial run (the tile's last active one): two loop-invariant lane masks and a scalar
-				// test per step, not a vector compare per step (as k_kw)
+				// one lane has a partial run (the tile's last active one): steps n < rl_last run in the lanes up to and
+				// including it, the others in the lanes before it (kw_pair)
 				const int last_l = (len - 1) / K, rl_last = len - last_l * K;
-				const bool upto = lane <= last_l, before = lane < last_l;
+				const uint64_t upto = __ballot (lane <= last_l), before = __ballot (lane < last_l);
 				v2f sj = 0;
-#pragma unroll
-				for (int n = 0; n < K; ++n) {
-					if (n < rl_last) { if (upto) { v2f y; KW_STEP (x[n], y); sj += y * y; } }
-					else             { if (before) { v2f y; KW_STEP (x[n], y); sj += y * y; } }
+				[&]<int... P> (std::integer_sequence<int, P...>) {
+					(kw_pair<2 * P> (x[2 * P], x[2 * P + 1], z1, z2, z3, z4, sj, a0, a1, a2, b1, b2, c3, c4, eps2, upto, before, rl_last), ...);
+				} (std::make_integer_sequence<int, K / 2> {});
+				if (rl_last & 1) {
+					// the partial lane stopped between the two steps of a pair: its shelving states sit swapped
+					const v2f w1 = mtrw::pick (z1, last_l), w2 = mtrw::pick (z2, last_l);
+					if (lane == last_l) { z1 = w2; z2 = w1; }
 				}
 				const float pw = mtrw::sum63 (a.gain_l * sj.x + a.gain_r * sj.y);
 				if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = pw;
