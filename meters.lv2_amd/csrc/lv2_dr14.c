@@ -1,13 +1,16 @@
-/* lv2_dr14.c — the DR-14 and "true peak + RMS" plugins of lib/meters_amd.so (src/dr14.c of the reference):
+/* lv2_dr14.c — the dr14mono / dr14stereo and TPnRMSmono / TPnRMSstereo plugins of lib/meters_amd.so.
  *
- *   dr14mono / dr14stereo       crest-factor "dynamic range" over 3 s windows (top 20 % of the RMS histogram
- *                               against the second-highest window peak), plus the bars below
- *   TPnRMSmono / TPnRMSstereo   the bars only: K-meter RMS and ballistic true peak with max hold
+ * A thin client of the batch engine: every number these plugins put on a port is computed on the GPU by
+ * an n_streams = 1 engine that carries three meters,
  *
- * Per channel the reference runs a Kmeterdsp and a TruePeakdsp::process.  The true-peak meter (4x
- * interpolation + attack / release ballistics) is the engine's TPBALLIST kernel on the GPU; the K-meter
- * one-poles and the window bookkeeping (one multiply-add per sample, a histogram insert every 3 s) stay on
- * the host like the other needle ballistics.  Ports as in src/dr14.c:27-43.
+ *   MTR_METER_TPBALLIST  TruePeakdsp::process, the ballistic true-peak bar      (reference: src/dr14.c:388, 421)
+ *   MTR_METER_KMETER     Kmeterdsp, the RMS bar and the held digital peak       (src/dr14.c:386, 422)
+ *   MTR_METER_DR14       3 s window sums, the 0.01 dB histogram, the top-20 %   (src/dr14.c:283-352, 394-411;
+ *                        score, the second-highest window peak, DR per channel   dr14 plugins only)
+ *
+ * and what is left here is the LV2 surface: the port map of lv2ttl/dr14*.ttl.in, the reset paths (GUI
+ * message, control port, transport start — src/dr14.c:262-281, 368-383), the true-peak maximum the host
+ * sees on the m_peak ports, and the "GUI attached" marker values (src/dr14.c:455-466).
  */
 #include <math.h>
 #include <stdio.h>
@@ -18,118 +21,51 @@
 #include "mtr_engine.h"
 #include "lv2_forge.h"
 #include "lv2_plugins.h"
-#include "lv2_dsp.h"
 
-enum { DR_CONTROL = 0, DR_HOST_TRANSPORT, DR_RESET, DR_BLKCNT, DR_INPUT0, DR_OUTPUT0, DR_V_PEAK0, DR_M_PEAK0,
-       DR_V_RMS0, DR_M_RMS0, DR_DR0, DR_INPUT1, DR_OUTPUT1, DR_V_PEAK1, DR_M_PEAK1, DR_V_RMS1, DR_M_RMS1, DR_DR1, DR_TOTAL };
-
-#define DR_CHANNELS 2
-#define DR_HISTBINS 8000                                     /* -80 dB .. 0 dB in .01 dB steps */
-#define MAXF(a, b) ((a) > (b) ? (a) : (b))
-#define MINF(a, b) ((a) < (b) ? (a) : (b))
+/* port indices, lv2ttl/dr14stereo.ttl.in (mono stops after the first channel's block) */
+enum {
+	PORT_ATOM_IN = 0, PORT_FOLLOW_TRANSPORT, PORT_RESET, PORT_BLOCKS,
+	PORT_CH0 = 4,           /* per channel: in, out, peak bar, peak max, rms bar, rms max / score, dr */
+	PORT_CH_STRIDE = 7,
+	PORT_DR_TOTAL = 18,
+	PORT_COUNT = 19
+};
+enum { CH_IN = 0, CH_OUT, CH_PEAK_BAR, CH_PEAK_MAX, CH_RMS_BAR, CH_RMS_MAX, CH_DR };
 
 typedef struct {
-	const LV2_Atom_Sequence* control;
-	float* p_follow_host_transport;
-	float* p_reset_button;
-	float* p_block_count;
-	float* p_input[DR_CHANNELS];
-	float* p_output[DR_CHANNELS];
-	float* p_v_rms[DR_CHANNELS];
-	float* p_v_peak[DR_CHANNELS];
-	float* p_m_rms[DR_CHANNELS];
-	float* p_m_peak[DR_CHANNELS];
-	float* p_dr[DR_CHANNELS];
-	float* p_dr_total;
+	void*       port[PORT_COUNT];
+	mtr_engine* engine;
+	ForgeUrids  urid;
+	LV2_URID    urid_reset;
+	uint32_t    channels;
+	int         with_dr;            /* dr14* (1) or TPnRMS* (0) */
+	int         rolling;            /* host transport state, from time:Position */
+	int         gui_attached;
+	float       tp_max[2];          /* maximum of the raw true peak since the last reset (linear) */
+} DrPlugin;
 
-	ForgeUrids u;
-	LV2_URID mtr_dr14reset;
-	uint32_t n_channels;
-	double rate;
-	uint64_t n_sample_cnt;
-	int follow_host_transport, tranport_rolling, reinit_gui, dr_operation_mode;
+static float to_db (float lin) { return lin < .0001f ? -80.f : 20.f * log10f (lin); }     /* the reference's -80 dB floor, :235-238 */
 
-	float m_dbtp[DR_CHANNELS], m_peak[DR_CHANNELS], m_rms[DR_CHANNELS];
-	uint64_t sample_count, num_fragments;
-	Kmeter km[DR_CHANNELS];
-	float rms_sum[DR_CHANNELS], peak_cur[DR_CHANNELS], peak_hist[DR_CHANNELS][2];
-	uint32_t* hist[DR_CHANNELS];
-	mtr_engine* amd;
-} Dr14;
+static float* fport (DrPlugin* p, uint32_t ch, int which) { return (float*) p->port[PORT_CH0 + PORT_CH_STRIDE * ch + which]; }
 
-static float coeff_to_db (const float coeff) { return coeff < .0001 ? -80 : 20 * log10f (coeff); }   /* :235-238 */
-static float db_to_coeff (const float db) { return db <= -80 ? 0 : powf (10, 0.05 * db); }          /* :240-243 */
-
-static void reset_peaks (Dr14* self)                         /* :245-260 */
+/* everything reset_peaks touches (:245-260) lives in the engine, except the true-peak maximum */
+static void clear_meters (DrPlugin* p)
 {
-	for (uint32_t c = 0; c < self->n_channels; ++c) {
-		self->m_peak[c] = -81;
-		self->m_rms[c] = -81;
-		self->m_dbtp[c] = 0;
-		self->rms_sum[c] = 0;
-		self->peak_cur[c] = 0;
-		self->peak_hist[c][0] = self->peak_hist[c][1] = 0;
-		km_reset (&self->km[c]);
-		if (self->dr_operation_mode) memset (self->hist[c], 0, DR_HISTBINS * sizeof (int32_t));
-	}
-	self->sample_count = 0;
-	self->num_fragments = 0;
-}
-
-/* one 3 s window is complete, :283-352 */
-static void calc_rms_score (Dr14* self)
-{
-	int silent = 1;
-	for (uint32_t c = 0; c < self->n_channels; ++c)
-		if (self->rms_sum[c] > 1e-9 * (float) self->n_sample_cnt) silent = 0;
-	if (silent) {                                            /* silence is not added to the histogram */
-		for (uint32_t c = 0; c < self->n_channels; ++c) self->rms_sum[c] = 0;
-		return;
-	}
-	self->num_fragments++;
-	const uint32_t m_cut = MAXF (1, floorf (self->num_fragments / 5.0));   /* top 20 % */
-	for (uint32_t c = 0; c < self->n_channels; ++c) {
-		const float rms = sqrt (2.f * self->rms_sum[c] / (float) self->n_sample_cnt);
-		self->rms_sum[c] = 0;
-		int bin = rintf (100.f * (80.f + coeff_to_db (rms))) - 1;
-		if (bin >= DR_HISTBINS) bin = DR_HISTBINS - 1;
-		if (bin > 0) self->hist[c][bin]++;
-
-		uint32_t n_cut = 0;
-		float rms_score = 0;
-		if (self->num_fragments > 2) {                       /* RMS average of the top bins, via coefficients */
-			for (int32_t b = DR_HISTBINS - 1; b > 0 && n_cut < m_cut; --b) {
-				const uint32_t bc = self->hist[c][b];
-				if (bc == 0) continue;
-				const float cd = db_to_coeff ((b - DR_HISTBINS + 1) / 100.0);
-				rms_score += cd * cd * (float) bc;
-				n_cut += bc;
-			}
-		}
-		self->m_rms[c] = n_cut > 0 ? coeff_to_db (sqrtf (rms_score / n_cut)) : -81;
-
-		/* the second-highest raw peak of all windows */
-		if (self->peak_cur[c] >= self->peak_hist[c][0]) {
-			self->peak_hist[c][1] = self->peak_hist[c][0];
-			self->peak_hist[c][0] = self->peak_cur[c];
-		} else if (self->peak_cur[c] > self->peak_hist[c][1]) {
-			self->peak_hist[c][1] = self->peak_cur[c];
-		}
-		self->peak_cur[c] = 0;
-		self->m_peak[c] = self->num_fragments > 2 ? coeff_to_db (self->peak_hist[c][1]) : -81;
-	}
+	p->tp_max[0] = p->tp_max[1] = 0.f;
+	mtr_engine_kmeter_reset (p->engine);
+	if (p->with_dr) mtr_engine_dr14_reset (p->engine);
 }
 
 LV2_Handle dr14_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features)
 {
 	(void) path;
-	uint32_t n_channels;
-	int dr_mode;
-	if (!strcmp (d->URI, MTR_URI "dr14stereo"))        { n_channels = 2; dr_mode = 1; }
-	else if (!strcmp (d->URI, MTR_URI "dr14mono"))     { n_channels = 1; dr_mode = 1; }
-	else if (!strcmp (d->URI, MTR_URI "TPnRMSstereo")) { n_channels = 2; dr_mode = 0; }
-	else if (!strcmp (d->URI, MTR_URI "TPnRMSmono"))   { n_channels = 1; dr_mode = 0; }
-	else return NULL;
+	static const struct { const char* name; uint32_t channels; int with_dr; } kinds[] = {
+		{ MTR_URI "dr14mono", 1, 1 }, { MTR_URI "dr14stereo", 2, 1 }, { MTR_URI "TPnRMSmono", 1, 0 }, { MTR_URI "TPnRMSstereo", 2, 0 },
+	};
+	int kind = -1;
+	for (int i = 0; i < 4; ++i) if (!strcmp (d->URI, kinds[i].name)) kind = i;
+	if (kind < 0) return NULL;
+
 	LV2_URID_Map* map = NULL;
 	for (int i = 0; features && features[i]; ++i)
 		if (!strcmp (features[i]->URI, LV2_URID__map)) map = (LV2_URID_Map*) features[i]->data;
@@ -137,160 +73,108 @@ LV2_Handle dr14_instantiate (const LV2_Descriptor* d, double rate, const char* p
 		fprintf (stderr, "DR14LV2 error: Host does not support urid:map\n");
 		return NULL;
 	}
-	Dr14* self = (Dr14*) calloc (1, sizeof (Dr14));
-	if (!self) return NULL;
-	self->n_channels = n_channels;
-	self->dr_operation_mode = dr_mode;
-	self->rate = rate;
-	forge_map_urids (map, &self->u);
-	self->mtr_dr14reset = map->map (map->handle, MTR_URI "dr14reset");
-	self->follow_host_transport = 1;
-	self->n_sample_cnt = (uint64_t) rintf (rate * 3.0);
-	for (uint32_t c = 0; c < n_channels; ++c) {
-		km_init (&self->km[c], (float) rate);
-		self->m_rms[c] = -81;
-		self->m_peak[c] = -81;
-		if (dr_mode) {
-			self->hist[c] = (uint32_t*) calloc (DR_HISTBINS, sizeof (uint32_t));
-			if (!self->hist[c]) { free (self->hist[0]); free (self); return NULL; }
-		}
-	}
+	DrPlugin* p = (DrPlugin*) calloc (1, sizeof (DrPlugin));
+	if (!p) return NULL;
+	p->channels = kinds[kind].channels;
+	p->with_dr = kinds[kind].with_dr;
+	forge_map_urids (map, &p->urid);
+	p->urid_reset = map->map (map->handle, MTR_URI "dr14reset");
+
 	mtr_config cfg;
 	memset (&cfg, 0, sizeof (cfg));
 	cfg.struct_size = sizeof (cfg);
-	cfg.meters = MTR_METER_TPBALLIST;
+	cfg.meters = MTR_METER_TPBALLIST | MTR_METER_KMETER | (p->with_dr ? MTR_METER_DR14 : 0u);
 	cfg.n_streams = 1;
-	cfg.n_channels = n_channels;
+	cfg.n_channels = p->channels;
 	cfg.sample_rate = (float) rate;
-	if (mtr_engine_create (&cfg, &self->amd) != MTR_OK) {
+	if (mtr_engine_create (&cfg, &p->engine) != MTR_OK) {
 		fprintf (stderr, "meters_amd: %s: %s\n", d->URI, mtr_last_error ());
-		free (self->hist[0]); free (self->hist[1]); free (self);
+		free (p);
 		return NULL;
 	}
-	return self;
+	return p;
 }
 
 void dr14_connect_port (LV2_Handle h, uint32_t port, void* data)
 {
-	Dr14* self = (Dr14*) h;
-	switch (port) {
-	case DR_CONTROL:        self->control = (const LV2_Atom_Sequence*) data; break;
-	case DR_HOST_TRANSPORT: self->p_follow_host_transport = (float*) data; break;
-	case DR_RESET:          self->p_reset_button = (float*) data; break;
-	case DR_BLKCNT:         self->p_block_count = (float*) data; break;
-	case DR_INPUT0:  self->p_input[0] = (float*) data; break;
-	case DR_OUTPUT0: self->p_output[0] = (float*) data; break;
-	case DR_V_RMS0:  self->p_v_rms[0] = (float*) data; break;
-	case DR_M_RMS0:  self->p_m_rms[0] = (float*) data; break;
-	case DR_V_PEAK0: self->p_v_peak[0] = (float*) data; break;
-	case DR_M_PEAK0: self->p_m_peak[0] = (float*) data; break;
-	case DR_DR0:     self->p_dr[0] = (float*) data; break;
-	case DR_TOTAL:   self->p_dr_total = (float*) data; break;
-	case DR_INPUT1:  self->p_input[1] = (float*) data; break;
-	case DR_OUTPUT1: self->p_output[1] = (float*) data; break;
-	case DR_V_RMS1:  self->p_v_rms[1] = (float*) data; break;
-	case DR_M_RMS1:  self->p_m_rms[1] = (float*) data; break;
-	case DR_V_PEAK1: self->p_v_peak[1] = (float*) data; break;
-	case DR_M_PEAK1: self->p_m_peak[1] = (float*) data; break;
-	case DR_DR1:     self->p_dr[1] = (float*) data; break;
-	default: break;
-	}
+	if (port < PORT_COUNT) ((DrPlugin*) h)->port[port] = data;
 }
 
-void dr14_run (LV2_Handle h, uint32_t n_samples)             /* :354-486 */
+void dr14_run (LV2_Handle h, uint32_t n_samples)
 {
-	Dr14* self = (Dr14*) h;
-	self->follow_host_transport = (*self->p_follow_host_transport != 0);
+	DrPlugin* p = (DrPlugin*) h;
+	const int follow = *(const float*) p->port[PORT_FOLLOW_TRANSPORT] != 0.f;
 
-	if (self->control) {                                      /* reset from the GUI, transport from the host */
-		FORGE_FOREACH_OBJECT (self->control, &self->u, obj) {
-			if (obj->body.otype == self->u.time_Position) {   /* parse_time_position :262-281 */
-				const LV2_Atom* speed = object_get (obj, self->u.time_speed);
-				if (speed && speed->type == self->u.atom_Float) {
-					const float ts = ((const LV2_Atom_Float*) speed)->body;
-					if (ts != 0 && !self->tranport_rolling && self->follow_host_transport) reset_peaks (self);
-					self->tranport_rolling = (ts != 0);
+	/* atom input: transport (a start clears the meters when the plugin follows the host), GUI reset, GUI on / off */
+	const LV2_Atom_Sequence* in = (const LV2_Atom_Sequence*) p->port[PORT_ATOM_IN];
+	if (in) {
+		FORGE_FOREACH_OBJECT (in, &p->urid, obj) {
+			const LV2_URID t = obj->body.otype;
+			if (t == p->urid.time_Position) {
+				const LV2_Atom* speed = object_get (obj, p->urid.time_speed);
+				if (speed && speed->type == p->urid.atom_Float) {
+					const int now = ((const LV2_Atom_Float*) speed)->body != 0.f;
+					if (now && !p->rolling && follow) clear_meters (p);
+					p->rolling = now;
 				}
-			}
-			if (obj->body.otype == self->mtr_dr14reset) reset_peaks (self);
-			if (obj->body.otype == self->u.mtr_meters_on)  self->reinit_gui = 1;
-			if (obj->body.otype == self->u.mtr_meters_off) self->reinit_gui = 0;
+			} else if (t == p->urid_reset)           clear_meters (p);
+			else if (t == p->urid.mtr_meters_on)     p->gui_attached = 1;
+			else if (t == p->urid.mtr_meters_off)    p->gui_attached = 0;
 		}
 	}
-	if (*self->p_reset_button != 0) reset_peaks (self);
+	if (*(const float*) p->port[PORT_RESET] != 0.f) clear_meters (p);
 
-	/* RMS bar (host), true-peak ballistics (GPU): Kmeterdsp::process + TruePeakdsp::process, :385-388 */
-	for (uint32_t c = 0; c < self->n_channels; ++c) km_process (&self->km[c], self->p_input[c], (int) n_samples);
-	const float* in[2] = { self->p_input[0], self->p_input[1] };
-	mtr_stream_result r;
-	memset (&r, 0, sizeof (r));
-	if (n_samples > 0) {
-		mtr_engine_process_planar_host (self->amd, in, n_samples);
-		mtr_engine_results (self->amd, 0, 1, &r);
-	}
+	/* the block through the engine, then the three meters' read-outs */
+	const float* chan[2] = { fport (p, 0, CH_IN), p->channels > 1 ? fport (p, 1, CH_IN) : NULL };
+	mtr_stream_result tp;
+	mtr_dr14_result dr;
+	float rms[2] = { 0.f, 0.f }, held[2] = { 0.f, 0.f };
+	memset (&tp, 0, sizeof (tp));
+	memset (&dr, 0, sizeof (dr));
+	int ok = 1;
+	if (n_samples > 0) ok = mtr_engine_process_planar_host (p->engine, chan, n_samples) == MTR_OK;
+	ok = ok && mtr_engine_results (p->engine, 0, 1, &tp) == MTR_OK
+	        && mtr_engine_kmeter_read (p->engine, 0, 1, rms, held) == MTR_OK
+	        && (!p->with_dr || mtr_engine_dr14_results (p->engine, 0, 1, &dr) == MTR_OK);
+	if (!ok) fprintf (stderr, "meters_amd: dr14: %s\n", mtr_last_error ());
 
-	/* 3 s non-overlapping windows, :394-410 */
-	if (self->dr_operation_mode) {
-		uint64_t scnt = self->sample_count;
-		const uint64_t slmt = self->n_sample_cnt;
-		for (uint32_t s = 0; s < n_samples; ++s) {
-			for (uint32_t c = 0; c < self->n_channels; ++c) {
-				const float v = self->p_input[c][s];
-				self->rms_sum[c] += v * v;
-				self->peak_cur[c] = MAXF (self->peak_cur[c], v);    /* the signed sample, as the reference */
-			}
-			if (++scnt > slmt) {
-				calc_rms_score (self);
-				scnt = 0;
-			}
-		}
-		self->sample_count = scnt;
-	}
-
-	/* values to ports, :413-451 */
-	float dr_total = 0;
-	int dr_valid = 0;
-	for (uint32_t c = 0; c < self->n_channels; ++c) {
-		float rv, rp;
-		const float pv = r.tpb_level[c], pp = r.tpb_peak[c];  /* TruePeakdsp::read (pv, pp) */
-		km_read (&self->km[c], &rv, &rp);
-		self->m_dbtp[c] = MAXF (self->m_dbtp[c], pp);
-		*self->p_v_rms[c]  = coeff_to_db (rv);
-		*self->p_v_peak[c] = coeff_to_db (pv);
-		*self->p_m_peak[c] = coeff_to_db (self->m_dbtp[c]);
-		if (self->dr_operation_mode) {
-			const float rdb = self->m_rms[c];
-			const float pdb = self->m_peak[c];
-			const float dr = MINF (0, pdb) - rdb;
-			if (rdb > -80 && pdb > -80) { dr_total += dr; dr_valid++; }
-			*self->p_dr[c] = (rdb > -80 && pdb > -80) ? MAXF (1, MINF (20, dr)) : 21;
-			*self->p_m_rms[c] = rdb;
+	for (uint32_t c = 0; c < p->channels && ok; ++c) {
+		if (tp.tpb_peak[c] > p->tp_max[c]) p->tp_max[c] = tp.tpb_peak[c];
+		*fport (p, c, CH_RMS_BAR)  = to_db (rms[c]);
+		*fport (p, c, CH_PEAK_BAR) = to_db (tp.tpb_level[c]);
+		*fport (p, c, CH_PEAK_MAX) = to_db (p->tp_max[c]);
+		if (p->with_dr) {
+			*fport (p, c, CH_RMS_MAX) = dr.m_rms[c];          /* the top-20 % RMS score, already in dB */
+			*fport (p, c, CH_DR)      = dr.dr[c];
 		} else {
-			*self->p_m_rms[c] = coeff_to_db (rp);
+			*fport (p, c, CH_RMS_MAX) = to_db (held[c]);      /* TPnRMS: the K-meter's held peak */
 		}
 	}
-	if (self->n_channels > 1 && self->dr_operation_mode)
-		*self->p_dr_total = dr_valid > 0 ? MAXF (1, MINF (20, dr_total / (float) dr_valid)) : 21;
-	*self->p_block_count = 3.0 * self->num_fragments;
+	if (ok) {
+		if (p->with_dr && p->channels > 1) *(float*) p->port[PORT_DR_TOTAL] = dr.dr_total;
+		*(float*) p->port[PORT_BLOCKS] = p->with_dr ? dr.block_count : 0.f;
+	}
 
-	if (self->reinit_gui) {                                   /* :455-466: markers that force a port change */
-		if (self->n_channels > 1 && self->dr_operation_mode) *self->p_dr_total = 21;
-		for (uint32_t c = 0; c < self->n_channels; ++c) {
-			*self->p_m_peak[c] = -100;
-			*self->p_m_rms[c] = -100;
-			if (self->dr_operation_mode) *self->p_dr[c] = 21;
+	if (p->gui_attached) {
+		/* a GUI that has just attached must see every port change once: out-of-range markers and a block count
+		 * that never repeats (src/dr14.c:455-466) */
+		for (uint32_t c = 0; c < p->channels; ++c) {
+			*fport (p, c, CH_PEAK_MAX) = -100.f;
+			*fport (p, c, CH_RMS_MAX)  = -100.f;
+			if (p->with_dr) *fport (p, c, CH_DR) = 21.f;
 		}
-		*self->p_block_count = -1 - (rand () & 0xffff);
+		if (p->with_dr && p->channels > 1) *(float*) p->port[PORT_DR_TOTAL] = 21.f;
+		*(float*) p->port[PORT_BLOCKS] = (float) (-1 - (rand () & 0xffff));
 	}
-	for (uint32_t c = 0; c < self->n_channels; ++c)
-		if (self->p_input[c] != self->p_output[c]) memcpy (self->p_output[c], self->p_input[c], sizeof (float) * n_samples);
+	for (uint32_t c = 0; c < p->channels; ++c) {
+		float* out = fport (p, c, CH_OUT);
+		if (out != chan[c]) memcpy (out, chan[c], sizeof (float) * n_samples);
+	}
 }
 
 void dr14_cleanup (LV2_Handle h)
 {
-	Dr14* self = (Dr14*) h;
-	if (self->amd) mtr_engine_destroy (self->amd);
-	free (self->hist[0]);
-	free (self->hist[1]);
-	free (self);
+	DrPlugin* p = (DrPlugin*) h;
+	if (p->engine) mtr_engine_destroy (p->engine);
+	free (p);
 }

@@ -50,69 +50,69 @@ typedef struct {
 	double rate;
 
 	int ui_active, send_state_to_ui;
-	int follow_transport_mode, tranport_rolling;             /* (sic) the reference's spelling */
-	int ebu_integrating, dbtp_enable;
-	uint32_t ui_settings;
+	int transport_mode, rolling;             /* (sic) the reference's spelling */
+	int integrating, dbtp_enable;
+	uint32_t ui_flags;
 
-	float *radarS, *radarM;
-	float radarSC, radarMC;
-	int radar_pos_cur, radar_pos_max;
-	uint32_t radar_spd_cur, radar_spd_max;
-	int radar_resync;
-	uint64_t integration_time;
-	int32_t histM[HIST_LEN], histS[HIST_LEN];
-	int32_t hist_maxM, hist_maxS;
-	float tp_max;
+	float *ring_s, *ring_m;
+	float acc_s, acc_m;
+	int ring_pos, ring_len;
+	uint32_t ring_acc, ring_span;
+	int resend_at;
+	uint64_t integ_frames;
+	int32_t sent_m[HIST_LEN], sent_s[HIST_LEN];
+	int32_t hmax_m, hmax_s;
+	float peak_db;
 
 	mtr_engine* amd;
 	int32_t devM[HIST_LEN], devS[HIST_LEN];                  /* the engine's histograms, fetched per cycle */
 } Ebu;
 
 /* ---- helpers of the reference, src/ebulv2.cc:44-112 ---------------------------------------------- */
-static void ebu_reset (Ebu* self)
+static void ebu_reset (Ebu* p)
 {
-	mtr_engine_integr_reset (self->amd);
+	mtr_engine_integr_reset (p->amd);
 	/* Not in the reference's ebu_reset: its TruePeakdsp objects are never reset, but their read() returns
-	 * the peak since the previous read, so tp_max = -inf below forgets the past there too. */
-	mtr_engine_truepeak_reset (self->amd);
-	kv_message (&self->fg, CTL_LV2_RESETRADAR, 0);
-	for (int i = 0; i < self->radar_pos_max; ++i) { self->radarS[i] = -INFINITY; self->radarM[i] = -INFINITY; }
-	memset (self->histM, 0, sizeof (self->histM));
-	memset (self->histS, 0, sizeof (self->histS));
-	self->radar_pos_cur = 0;
-	self->integration_time = 0;
-	self->hist_maxM = 0;
-	self->hist_maxS = 0;
-	self->tp_max = -INFINITY;
+	 * the peak since the previous read, so peak_db = -inf below forgets the past there too. */
+	mtr_engine_truepeak_reset (p->amd);
+	kv_message (&p->fg, CTL_LV2_RESETRADAR, 0);
+	for (int i = 0; i < p->ring_len; ++i) { p->ring_s[i] = -INFINITY; p->ring_m[i] = -INFINITY; }
+	memset (p->sent_m, 0, sizeof (p->sent_m));
+	memset (p->sent_s, 0, sizeof (p->sent_s));
+	p->ring_pos = 0;
+	p->integ_frames = 0;
+	p->hmax_m = 0;
+	p->hmax_s = 0;
+	p->peak_db = -INFINITY;
 }
 
-static void ebu_integrate (Ebu* self, int on)
+static void ebu_integrate (Ebu* p, int on)
 {
-	if (self->ebu_integrating == on) return;
+	if (p->integrating == on) return;
 	if (on) {
-		if (self->follow_transport_mode & 2) ebu_reset (self);
-		mtr_engine_integr_start (self->amd);
-		self->ebu_integrating = 1;
+		if (p->transport_mode & 2) ebu_reset (p);
+		mtr_engine_integr_start (p->amd);
+		p->integrating = 1;
 	} else {
-		mtr_engine_integr_pause (self->amd);
-		self->ebu_integrating = 0;
+		mtr_engine_integr_pause (p->amd);
+		p->integrating = 0;
 	}
 }
 
-static void ebu_set_radarspeed (Ebu* self, float seconds)
+static void ebu_set_radarspeed (Ebu* p, float seconds)
 {
-	self->radar_spd_max = (uint32_t) rint (seconds * self->rate / self->radar_pos_max);
-	if (self->radar_spd_max < 4096) self->radar_spd_max = 4096;
+	p->ring_span = (uint32_t) rint (seconds * p->rate / p->ring_len);
+	if (p->ring_span < 4096) p->ring_span = 4096;
 }
 
-static void update_position (Ebu* self, const LV2_Atom_Object* obj)
+static void update_position (Ebu* p, const LV2_Atom_Object* obj)
 {
-	const LV2_Atom* speed = object_get (obj, self->u.f.time_speed);
-	if (speed && speed->type == self->u.f.atom_Float) {
+	const LV2_Atom* speed = object_get (obj, p->u.f.time_speed);
+	if (speed && speed->type == p->u.f.atom_Float) {
 		const float ts = ((const LV2_Atom_Float*) speed)->body;
-		if (ts != 0 && !self->tranport_rolling) { if (self->follow_transport_mode & 1) ebu_integrate (self, 1); }
-		if (ts == 0 && self->tranport_rolling)  { if (self->follow_transport_mode & 1) ebu_integrate (self, 0); }
-		self->tranport_rolling = (ts != 0);
+		if (ts != 0 && !p->rolling) { if (p->transport_mode & 1) ebu_integrate (p, 1); }
+		if (ts == 0 && p->rolling)  { if (p->transport_mode & 1) ebu_integrate (p, 0); }
+		p->rolling = (ts != 0);
 	}
 }
 
@@ -121,17 +121,17 @@ LV2_Handle ebur128_instantiate (const LV2_Descriptor* d, double rate, const char
 {
 	(void) path;
 	if (strcmp (d->URI, MTR_URI "EBUr128")) return NULL;
-	Ebu* self = (Ebu*) calloc (1, sizeof (Ebu));
-	if (!self) return NULL;
+	Ebu* p = (Ebu*) calloc (1, sizeof (Ebu));
+	if (!p) return NULL;
 	for (int i = 0; features && features[i]; ++i)
-		if (!strcmp (features[i]->URI, LV2_URID__map)) self->map = (LV2_URID_Map*) features[i]->data;
-	if (!self->map) {                                        /* src/ebulv2.cc:140-144 */
+		if (!strcmp (features[i]->URI, LV2_URID__map)) p->map = (LV2_URID_Map*) features[i]->data;
+	if (!p->map) {                                        /* src/ebulv2.cc:140-144 */
 		fprintf (stderr, "EBUrLV2 error: Host does not support urid:map\n");
-		free (self);
+		free (p);
 		return NULL;
 	}
-#define MAP(field, uri) self->u.field = self->map->map (self->map->handle, uri)
-	forge_map_urids (self->map, &self->u.f);
+#define MAP(field, uri) p->u.field = p->map->map (p->map->handle, uri)
+	forge_map_urids (p->map, &p->u.f);
 	MAP (mtr_ebulevels, MTR_URI "ebulevels");
 	MAP (ebu_loudnessM, MTR_URI "ebu_loudnessM"); MAP (ebu_maxloudnM, MTR_URI "ebu_maxloudnM");
 	MAP (ebu_loudnessS, MTR_URI "ebu_loudnessS"); MAP (ebu_maxloudnS, MTR_URI "ebu_maxloudnS");
@@ -143,17 +143,17 @@ LV2_Handle ebur128_instantiate (const LV2_Descriptor* d, double rate, const char
 	MAP (rdr_radarpoint, MTR_URI "rdr_radarpoint"); MAP (rdr_pointpos, MTR_URI "rdr_pointpos");
 	MAP (rdr_pos_cur, MTR_URI "rdr_pos_cur"); MAP (rdr_pos_max, MTR_URI "rdr_pos_max");
 #undef MAP
-	self->rate = rate;
-	self->radar_pos_max = 360;
-	self->radar_resync = -1;
-	self->ui_settings = 8;
-	self->radarS = (float*) malloc (self->radar_pos_max * sizeof (float));
-	self->radarM = (float*) malloc (self->radar_pos_max * sizeof (float));
-	if (!self->radarS || !self->radarM) { free (self->radarS); free (self->radarM); free (self); return NULL; }
-	self->radarSC = self->radarMC = -INFINITY;
-	for (int i = 0; i < self->radar_pos_max; ++i) { self->radarS[i] = -INFINITY; self->radarM[i] = -INFINITY; }
-	ebu_set_radarspeed (self, 2.0f * 60.0f);
-	self->tp_max = -INFINITY;
+	p->rate = rate;
+	p->ring_len = 360;
+	p->resend_at = -1;
+	p->ui_flags = 8;
+	p->ring_s = (float*) malloc (p->ring_len * sizeof (float));
+	p->ring_m = (float*) malloc (p->ring_len * sizeof (float));
+	if (!p->ring_s || !p->ring_m) { free (p->ring_s); free (p->ring_m); free (p); return NULL; }
+	p->acc_s = p->acc_m = -INFINITY;
+	for (int i = 0; i < p->ring_len; ++i) { p->ring_s[i] = -INFINITY; p->ring_m[i] = -INFINITY; }
+	ebu_set_radarspeed (p, 2.0f * 60.0f);
+	p->peak_db = -INFINITY;
 
 	mtr_config cfg;
 	memset (&cfg, 0, sizeof (cfg));
@@ -162,97 +162,97 @@ LV2_Handle ebur128_instantiate (const LV2_Descriptor* d, double rate, const char
 	cfg.n_streams = 1;
 	cfg.n_channels = 2;
 	cfg.sample_rate = (float) rate;
-	if (mtr_engine_create (&cfg, &self->amd) != MTR_OK) {
+	if (mtr_engine_create (&cfg, &p->amd) != MTR_OK) {
 		fprintf (stderr, "meters_amd: EBUr128: %s\n", mtr_last_error ());
-		free (self->radarS); free (self->radarM); free (self);
+		free (p->ring_s); free (p->ring_m); free (p);
 		return NULL;
 	}
-	return self;
+	return p;
 }
 
 void ebur128_connect_port (LV2_Handle h, uint32_t port, void* data)
 {
-	Ebu* self = (Ebu*) h;
+	Ebu* p = (Ebu*) h;
 	switch (port) {
-	case EBU_INPUT0:  self->input[0] = (float*) data; break;
-	case EBU_OUTPUT0: self->output[0] = (float*) data; break;
-	case EBU_INPUT1:  self->input[1] = (float*) data; break;
-	case EBU_OUTPUT1: self->output[1] = (float*) data; break;
-	case EBU_NOTIFY:  self->notify = (LV2_Atom_Sequence*) data; break;
-	case EBU_CONTROL: self->control = (const LV2_Atom_Sequence*) data; break;
+	case EBU_INPUT0:  p->input[0] = (float*) data; break;
+	case EBU_OUTPUT0: p->output[0] = (float*) data; break;
+	case EBU_INPUT1:  p->input[1] = (float*) data; break;
+	case EBU_OUTPUT1: p->output[1] = (float*) data; break;
+	case EBU_NOTIFY:  p->notify = (LV2_Atom_Sequence*) data; break;
+	case EBU_CONTROL: p->control = (const LV2_Atom_Sequence*) data; break;
 	default: break;
 	}
 }
 
-static void radar_point (Ebu* self, float m, float s, int pos)
+static void radar_point (Ebu* p, float m, float s, int pos)
 {
 	ObjFrame fr;
-	if (!obj_begin (&self->fg, &fr, self->u.rdr_radarpoint)) return;
-	prop_f (&self->fg, self->u.ebu_loudnessM, m);
-	prop_f (&self->fg, self->u.ebu_loudnessS, s);
-	prop_i (&self->fg, self->u.rdr_pointpos, pos);
-	prop_i (&self->fg, self->u.rdr_pos_cur, self->radar_pos_cur);
-	prop_i (&self->fg, self->u.rdr_pos_max, self->radar_pos_max);
-	obj_end (&self->fg, &fr);
+	if (!obj_begin (&p->fg, &fr, p->u.rdr_radarpoint)) return;
+	prop_f (&p->fg, p->u.ebu_loudnessM, m);
+	prop_f (&p->fg, p->u.ebu_loudnessS, s);
+	prop_i (&p->fg, p->u.rdr_pointpos, pos);
+	prop_i (&p->fg, p->u.rdr_pos_cur, p->ring_pos);
+	prop_i (&p->fg, p->u.rdr_pos_max, p->ring_len);
+	obj_end (&p->fg, &fr);
 }
 
 void ebur128_run (LV2_Handle h, uint32_t n_samples)
 {
-	Ebu* self = (Ebu*) h;
-	const uint32_t capacity = self->notify->atom.size;
-	Forge* const fg = &self->fg;
-	forge_begin (fg, self->notify, &self->u.f);
+	Ebu* p = (Ebu*) h;
+	const uint32_t capacity = p->notify->atom.size;
+	Forge* const fg = &p->fg;
+	forge_begin (fg, p->notify, &p->u.f);
 
-	if (self->send_state_to_ui && self->ui_active) {          /* :248-255 */
-		self->send_state_to_ui = 0;
-		kv_message (fg, CTL_LV2_FTM, (float) self->follow_transport_mode);
-		kv_message (fg, CTL_LV2_RADARTIME, (float) (self->radar_pos_max * self->radar_spd_max / self->rate));
-		kv_message (fg, CTL_UISETTINGS, (float) self->ui_settings);
+	if (p->send_state_to_ui && p->ui_active) {          /* :248-255 */
+		p->send_state_to_ui = 0;
+		kv_message (fg, CTL_LV2_FTM, (float) p->transport_mode);
+		kv_message (fg, CTL_LV2_RADARTIME, (float) (p->ring_len * p->ring_span / p->rate));
+		kv_message (fg, CTL_UISETTINGS, (float) p->ui_flags);
 	}
 
 	/* incoming events, :257-331 */
-	if (self->control) {
-		FORGE_FOREACH_OBJECT (self->control, &self->u.f, obj) {
-			if (obj->body.otype == self->u.f.time_Position) {
-				update_position (self, obj);
-			} else if (obj->body.otype == self->u.f.mtr_meters_on) {
-				self->ui_active = 1;
-				self->send_state_to_ui = 1;
-				self->radar_resync = 0;
-				memset (self->histM, 0, sizeof (self->histM));          /* resync histogram */
-				memset (self->histS, 0, sizeof (self->histS));
-				self->hist_maxM = 0;
-				self->hist_maxS = 0;
-			} else if (obj->body.otype == self->u.f.mtr_meters_off) {
-				self->ui_active = 0;
-			} else if (obj->body.otype == self->u.f.mtr_meters_cfg) {
+	if (p->control) {
+		FORGE_FOREACH_OBJECT (p->control, &p->u.f, obj) {
+			if (obj->body.otype == p->u.f.time_Position) {
+				update_position (p, obj);
+			} else if (obj->body.otype == p->u.f.mtr_meters_on) {
+				p->ui_active = 1;
+				p->send_state_to_ui = 1;
+				p->resend_at = 0;
+				memset (p->sent_m, 0, sizeof (p->sent_m));          /* resync histogram */
+				memset (p->sent_s, 0, sizeof (p->sent_s));
+				p->hmax_m = 0;
+				p->hmax_s = 0;
+			} else if (obj->body.otype == p->u.f.mtr_meters_off) {
+				p->ui_active = 0;
+			} else if (obj->body.otype == p->u.f.mtr_meters_cfg) {
 				int key; float val;
-				get_cc_key_value (&self->u.f, obj, &key, &val);
+				get_cc_key_value (&p->u.f, obj, &key, &val);
 				switch (key) {
-				case CTL_START: ebu_integrate (self, 1); break;
-				case CTL_PAUSE: ebu_integrate (self, 0); break;
-				case CTL_RESET: ebu_reset (self); break;
+				case CTL_START: ebu_integrate (p, 1); break;
+				case CTL_PAUSE: ebu_integrate (p, 0); break;
+				case CTL_RESET: ebu_reset (p); break;
 				case CTL_TRANSPORTSYNC:
 					if (val == 1) {
-						self->follow_transport_mode |= 1;
-						if (self->tranport_rolling != self->ebu_integrating) ebu_integrate (self, self->tranport_rolling);
+						p->transport_mode |= 1;
+						if (p->rolling != p->integrating) ebu_integrate (p, p->rolling);
 					} else {
-						self->follow_transport_mode &= ~1;
+						p->transport_mode &= ~1;
 					}
 					break;
 				case CTL_AUTORESET:
-					if (val == 1) self->follow_transport_mode |= 2; else self->follow_transport_mode &= ~2;
+					if (val == 1) p->transport_mode |= 2; else p->transport_mode &= ~2;
 					break;
 				case CTL_RADARTIME:
 					if (val >= 30 && val <= 600) {
-						ebu_set_radarspeed (self, val);
-						if (self->radar_spd_max < 2 * n_samples) self->radar_spd_max = 2 * n_samples;
+						ebu_set_radarspeed (p, val);
+						if (p->ring_span < 2 * n_samples) p->ring_span = 2 * n_samples;
 					}
-					kv_message (fg, CTL_LV2_RADARTIME, (float) (self->radar_pos_max * self->radar_spd_max / self->rate));
+					kv_message (fg, CTL_LV2_RADARTIME, (float) (p->ring_len * p->ring_span / p->rate));
 					break;
 				case CTL_UISETTINGS:
-					self->ui_settings = (uint32_t) val;
-					self->dbtp_enable = (self->ui_settings & 64) ? 1 : 0;
+					p->ui_flags = (uint32_t) val;
+					p->dbtp_enable = (p->ui_flags & 64) ? 1 : 0;
 					break;
 				default: break;
 				}
@@ -261,123 +261,123 @@ void ebur128_run (LV2_Handle h, uint32_t n_samples)
 	}
 
 	/* audio, :340-347: one batch-of-one launch; results come back in one record */
-	const float* in[2] = { self->input[0], self->input[1] };
-	if (n_samples > 0) mtr_engine_process_planar_host (self->amd, in, n_samples);
+	const float* in[2] = { p->input[0], p->input[1] };
+	if (n_samples > 0) mtr_engine_process_planar_host (p->amd, in, n_samples);
 	mtr_stream_result r;
 	memset (&r, 0, sizeof (r));
-	mtr_engine_results (self->amd, 0, 1, &r);
+	mtr_engine_results (p->amd, 0, 1, &r);
 	const float lm = r.loudness_M, ls = r.loudness_S;
 
-	if (self->dbtp_enable) {                                  /* :360-367 */
+	if (p->dbtp_enable) {                                  /* :360-367 */
 		const float tp0 = r.truepeak_call[0], tp1 = r.truepeak_call[1];
 		const float tpm = tp0 > tp1 ? tp0 : tp1;
 		const float tp = tpm == 0 ? -INFINITY : (float) (20.0 * log10f (tpm));
-		if (tp > self->tp_max) self->tp_max = tp;
+		if (tp > p->peak_db) p->peak_db = tp;
 	} else {
-		self->tp_max = -INFINITY;
+		p->peak_db = -INFINITY;
 	}
 
-	if (self->radar_resync >= 0) {                            /* :369-388 */
+	if (p->resend_at >= 0) {                            /* :369-388 */
 		int batch = ((int) capacity - 512) / 192;
 		if (batch > 16) batch = 16;
-		for (int i = 0; i < batch; i++, self->radar_resync++) {
-			if (self->radar_resync >= self->radar_pos_max) {
-				self->radar_resync = -1;
+		for (int i = 0; i < batch; i++, p->resend_at++) {
+			if (p->resend_at >= p->ring_len) {
+				p->resend_at = -1;
 				kv_message (fg, CTL_LV2_RESYNCDONE, 0);
 				break;
 			}
-			radar_point (self, self->radarM[self->radar_resync], self->radarS[self->radar_resync], self->radar_resync);
+			radar_point (p, p->ring_m[p->resend_at], p->ring_s[p->resend_at], p->resend_at);
 		}
 	}
 
 	/* radar history, :390-423 (the second test reads `lm` in the reference too) */
-	if (lm > self->radarMC) self->radarMC = lm;
-	if (lm > self->radarSC) self->radarSC = ls;
-	if (self->ebu_integrating) self->integration_time += n_samples;
-	self->radar_spd_cur += n_samples;
-	if (self->radar_spd_cur > self->radar_spd_max) {
-		if (self->ui_active) radar_point (self, self->radarMC, self->radarSC, self->radar_pos_cur);
-		self->radarM[self->radar_pos_cur] = self->radarMC;
-		self->radarS[self->radar_pos_cur] = self->radarSC;
-		self->radar_spd_cur = self->radar_spd_cur % self->radar_spd_max;
-		self->radar_pos_cur = (self->radar_pos_cur + 1) % self->radar_pos_max;
-		self->radarSC = self->radarMC = -INFINITY;
+	if (lm > p->acc_m) p->acc_m = lm;
+	if (lm > p->acc_s) p->acc_s = ls;
+	if (p->integrating) p->integ_frames += n_samples;
+	p->ring_acc += n_samples;
+	if (p->ring_acc > p->ring_span) {
+		if (p->ui_active) radar_point (p, p->acc_m, p->acc_s, p->ring_pos);
+		p->ring_m[p->ring_pos] = p->acc_m;
+		p->ring_s[p->ring_pos] = p->acc_s;
+		p->ring_acc = p->ring_acc % p->ring_span;
+		p->ring_pos = (p->ring_pos + 1) % p->ring_len;
+		p->acc_s = p->acc_m = -INFINITY;
 	}
 
-	if (self->ui_active) {                                    /* histogram diffs, :425-462 */
+	if (p->ui_active) {                                    /* histogram diffs, :425-462 */
 		int msgtx = 0;
 		if (r.hist_M_count > 10 && r.hist_S_count > 10
-		    && mtr_engine_histograms (self->amd, 0, 1, self->devM, self->devS) == MTR_OK) {
+		    && mtr_engine_histograms (p->amd, 0, 1, p->devM, p->devS) == MTR_OK) {
 			int max_changed = 0;
 			for (int i = 110; i < 650; i++) {
-				const int32_t vm = self->devM[i], vs = self->devS[i];
+				const int32_t vm = p->devM[i], vs = p->devS[i];
 				if (capacity - forge_used (fg) <= 512) break;
-				if (self->histM[i] != vm || self->histS[i] != vs) {
+				if (p->sent_m[i] != vm || p->sent_s[i] != vs) {
 					if (msgtx++ > 16) break;                  /* limit max data-rate */
-					self->histM[i] = vm;
-					self->histS[i] = vs;
+					p->sent_m[i] = vm;
+					p->sent_s[i] = vs;
 					ObjFrame fr;
-					if (obj_begin (fg, &fr, self->u.rdr_histpoint)) {
-						prop_i (fg, self->u.ebu_loudnessM, vm);
-						prop_i (fg, self->u.ebu_loudnessS, vs);
-						prop_i (fg, self->u.rdr_pointpos, i);
+					if (obj_begin (fg, &fr, p->u.rdr_histpoint)) {
+						prop_i (fg, p->u.ebu_loudnessM, vm);
+						prop_i (fg, p->u.ebu_loudnessS, vs);
+						prop_i (fg, p->u.rdr_pointpos, i);
 						obj_end (fg, &fr);
 					}
 				}
-				if (vm > self->hist_maxM) { self->hist_maxM = vm; max_changed = 1; }
-				if (vs > self->hist_maxS) { self->hist_maxS = vs; max_changed = 1; }
+				if (vm > p->hmax_m) { p->hmax_m = vm; max_changed = 1; }
+				if (vs > p->hmax_s) { p->hmax_s = vs; max_changed = 1; }
 			}
 			if (max_changed) {
 				ObjFrame fr;
-				if (obj_begin (fg, &fr, self->u.rdr_histogram)) {
-					prop_i (fg, self->u.ebu_loudnessM, self->hist_maxM);
-					prop_i (fg, self->u.ebu_loudnessS, self->hist_maxS);
+				if (obj_begin (fg, &fr, p->u.rdr_histogram)) {
+					prop_i (fg, p->u.ebu_loudnessM, p->hmax_m);
+					prop_i (fg, p->u.ebu_loudnessS, p->hmax_s);
 					obj_end (fg, &fr);
 				}
 			}
 		}
 	}
 
-	if (self->ui_active) {                                    /* `ebulevels`, :464-482 */
+	if (p->ui_active) {                                    /* `ebulevels`, :464-482 */
 		ObjFrame fr;
-		if (obj_begin (fg, &fr, self->u.mtr_ebulevels)) {
-			prop_f (fg, self->u.ebu_loudnessM, lm);
-			prop_f (fg, self->u.ebu_maxloudnM, r.maxloudn_M);
-			prop_f (fg, self->u.ebu_loudnessS, ls);
-			prop_f (fg, self->u.ebu_maxloudnS, r.maxloudn_S);
-			prop_f (fg, self->u.ebu_integrated, r.integrated);
-			prop_f (fg, self->u.ebu_range_min, r.range_min);
-			prop_f (fg, self->u.ebu_range_max, r.range_max);
-			prop_f (fg, self->u.mtr_truepeak, self->tp_max);
-			prop_b (fg, self->u.ebu_integrating, self->ebu_integrating);
-			prop_f (fg, self->u.ebu_integr_time, (float) (self->integration_time / self->rate));
+		if (obj_begin (fg, &fr, p->u.mtr_ebulevels)) {
+			prop_f (fg, p->u.ebu_loudnessM, lm);
+			prop_f (fg, p->u.ebu_maxloudnM, r.maxloudn_M);
+			prop_f (fg, p->u.ebu_loudnessS, ls);
+			prop_f (fg, p->u.ebu_maxloudnS, r.maxloudn_S);
+			prop_f (fg, p->u.ebu_integrated, r.integrated);
+			prop_f (fg, p->u.ebu_range_min, r.range_min);
+			prop_f (fg, p->u.ebu_range_max, r.range_max);
+			prop_f (fg, p->u.mtr_truepeak, p->peak_db);
+			prop_b (fg, p->u.ebu_integrating, p->integrating);
+			prop_f (fg, p->u.ebu_integr_time, (float) (p->integ_frames / p->rate));
 			obj_end (fg, &fr);
 		}
 	}
 
 	for (int c = 0; c < 2; ++c)
-		if (self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
+		if (p->input[c] != p->output[c]) memcpy (p->output[c], p->input[c], sizeof (float) * n_samples);
 }
 
 void ebur128_cleanup (LV2_Handle h)
 {
-	Ebu* self = (Ebu*) h;
-	if (self->amd) mtr_engine_destroy (self->amd);
-	free (self->radarS);
-	free (self->radarM);
-	free (self);
+	Ebu* p = (Ebu*) h;
+	if (p->amd) mtr_engine_destroy (p->amd);
+	free (p->ring_s);
+	free (p->ring_m);
+	free (p);
 }
 
-/* ---- LV2 State, src/ebulv2.cc:514-553: one atom:Int = ui_settings | follow_transport_mode << 8 | radar_spd_max << 16 */
+/* ---- LV2 State, src/ebulv2.cc:514-553: one atom:Int = ui_flags | transport_mode << 8 | ring_span << 16 */
 static LV2_State_Status ebur128_save (LV2_Handle h, LV2_State_Store_Function store, LV2_State_Handle handle,
                                       uint32_t flags, const LV2_Feature* const* features)
 {
 	(void) flags; (void) features;
-	Ebu* self = (Ebu*) h;
-	uint32_t cfg = self->ui_settings;
-	cfg |= (uint32_t) self->follow_transport_mode << 8;
-	cfg |= self->radar_spd_max << 16;
-	store (handle, self->u.ebu_state, (void*) &cfg, sizeof (uint32_t), self->u.f.atom_Int, LV2_STATE_IS_POD | LV2_STATE_IS_PORTABLE);
+	Ebu* p = (Ebu*) h;
+	uint32_t cfg = p->ui_flags;
+	cfg |= (uint32_t) p->transport_mode << 8;
+	cfg |= p->ring_span << 16;
+	store (handle, p->u.ebu_state, (void*) &cfg, sizeof (uint32_t), p->u.f.atom_Int, LV2_STATE_IS_POD | LV2_STATE_IS_PORTABLE);
 	return LV2_STATE_SUCCESS;
 }
 
@@ -385,17 +385,17 @@ static LV2_State_Status ebur128_restore (LV2_Handle h, LV2_State_Retrieve_Functi
                                          uint32_t flags, const LV2_Feature* const* features)
 {
 	(void) flags; (void) features;
-	Ebu* self = (Ebu*) h;
+	Ebu* p = (Ebu*) h;
 	size_t size;
 	uint32_t type, valflags;
-	const void* value = retrieve (handle, self->u.ebu_state, &size, &type, &valflags);
-	if (value && size == sizeof (uint32_t) && type == self->u.f.atom_Int) {
+	const void* value = retrieve (handle, p->u.ebu_state, &size, &type, &valflags);
+	if (value && size == sizeof (uint32_t) && type == p->u.f.atom_Int) {
 		const uint32_t cfg = *((const uint32_t*) value);
-		self->ui_settings = cfg & 0xff;
-		self->follow_transport_mode = (cfg >> 8) & 0x3;
-		self->radar_spd_max = cfg >> 16;
-		self->dbtp_enable = (self->ui_settings & 64) ? 1 : 0;
-		self->send_state_to_ui = 1;
+		p->ui_flags = cfg & 0xff;
+		p->transport_mode = (cfg >> 8) & 0x3;
+		p->ring_span = cfg >> 16;
+		p->dbtp_enable = (p->ui_flags & 64) ? 1 : 0;
+		p->send_state_to_ui = 1;
 	}
 	return LV2_STATE_SUCCESS;
 }

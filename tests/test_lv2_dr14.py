@@ -1,6 +1,14 @@
-"""dr14 / TPnRMS plugins through the LV2 ABI against the oracle's restatement of src/dr14.c (mo_dr14_*: K-meter and
-window bookkeeping on the CPU — must agree exactly — and TruePeakdsp::process, which the plugin runs on the GPU:
-2e-5 dB on the true-peak bars)."""
+"""dr14 / TPnRMS plugins through the LV2 ABI against the oracle's restatement of src/dr14.c (mo_dr14_*).  The plugin
+is a thin client of the batch engine (TPBALLIST + KMETER + DR14 meters, all on the GPU), so every port carries
+a stated tolerance:
+  * true-peak bars (TruePeakdsp::process):       2e-5 dB
+  * K-meter RMS bar (Kmeterdsp, f32 two-pole):   2e-4 dB (the engine sums the squares in double: 1e-5 relative)
+  * K-meter held peak (TPnRMS m_rms port):       1e-5 relative in dB (an ulp of the fall-back factor)
+  * DR-14 score, DR per channel, DR total:       0.01 dB = the contract = ONE bin of the reference's 0.01 dB histogram:
+    a window's RMS is binned after summing 144 001 squares — sequentially in f32 in the reference, in double on
+    the GPU — and the two sums differ by ~2e-5 relative (1e-4 dB), which moves a window across a bin edge once
+    in ~100 windows; the score is an average over bins, so it moves by at most that one bin.  Measured here: 0.
+  * window count: exact."""
 import ctypes as C
 
 import numpy as np
@@ -12,6 +20,7 @@ from _lv2host import Host, Instance, MTR_URI, forge_object, forge_sequence
 pytestmark = pytest.mark.gpu
 K = MTR_URI
 F = C.c_float
+DR_TOL = 0.01 + 1e-5        # one 0.01 dB histogram bin (module docstring), plus float slack
 
 
 class Ports(C.Structure):
@@ -61,7 +70,7 @@ def test_dr14_against_the_restatement(host, oracle, name, chn, dr_mode):
         inst.connect(18, total)
     empty = forge_sequence(host, [])
     want = Ports()
-    n_win = 0
+    n_win, worst = 0, 0.0
     for i, q in enumerate(range(0, xl.size - B + 1, B)):
         chans = [xl[q:q + B].copy(), xr[q:q + B].copy()][:chn]
         ctl = empty
@@ -78,18 +87,22 @@ def test_dr14_against_the_restatement(host, oracle, name, chn, dr_mode):
         ptrs = (C.c_void_p * 2)(*[ch.ctypes.data for ch in chans], *([None] * (2 - chn)))
         lib.mo_dr14_run(state, ptrs, B, C.byref(want))
         for c in range(chn):
-            assert ports["v_rms"][c][0] == np.float32(want.v_rms[c]), (i, c)
+            assert abs(ports["v_rms"][c][0] - want.v_rms[c]) <= 2e-4, (i, c, ports["v_rms"][c][0], want.v_rms[c])
             assert abs(ports["v_peak"][c][0] - want.v_peak[c]) <= 2e-5 * max(1.0, abs(want.v_peak[c])), (i, c, ports["v_peak"][c][0], want.v_peak[c])
             assert abs(ports["m_peak"][c][0] - want.m_peak[c]) <= 2e-5 * max(1.0, abs(want.m_peak[c])), (i, c)
-            assert ports["m_rms"][c][0] == np.float32(want.m_rms[c]), (i, c, ports["m_rms"][c][0], want.m_rms[c])
             if dr_mode:
-                assert ports["dr"][c][0] == np.float32(want.dr[c]), (i, c)
+                worst = max(worst, abs(ports["m_rms"][c][0] - want.m_rms[c]), abs(ports["dr"][c][0] - want.dr[c]))
+                assert abs(ports["m_rms"][c][0] - want.m_rms[c]) <= DR_TOL, (i, c, ports["m_rms"][c][0], want.m_rms[c])
+                assert abs(ports["dr"][c][0] - want.dr[c]) <= DR_TOL, (i, c, ports["dr"][c][0], want.dr[c])
+            else:
+                assert abs(ports["m_rms"][c][0] - want.m_rms[c]) <= 1e-5 * max(1.0, abs(want.m_rms[c])), (i, c, ports["m_rms"][c][0], want.m_rms[c])
         if chn == 2 and dr_mode:
-            assert total[0] == np.float32(want.dr_total), i
+            assert abs(total[0] - want.dr_total) <= DR_TOL, i
         assert blk[0] == np.float32(want.block_count), i
         n_win = max(n_win, int(want.block_count) // 3)
     if dr_mode:
         assert n_win >= 2                                     # windows were completed between the resets
+        print("worst DR-14 port deviation [dB]:", worst)
     # the GUI attaching: marker values that force a change on the ports (src/dr14.c:455-466)
     inst.connect(0, forge_sequence(host, [forge_object(host, K + "meteron", [])]))
     inst.run(B)
