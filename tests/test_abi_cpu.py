@@ -3,6 +3,7 @@ declares, its host-side set-up math matches the golden vectors bit-for-bit, and 
 run without a GPU instead of falling back to anything.  No compute kernels are launched."""
 import ctypes as C
 import os
+import re
 
 import numpy as np
 import pytest
@@ -27,12 +28,21 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_product_never_touches_the_oracle():
+    """Nothing the product ships (package, public headers) names the oracle, the reference-built checker
+    (oracle/_ref/libmeters_ref.so — it travels to the GPU box for bench.py's cpu_baseline) or loads a library by
+    name at run time: the only dlopen-like call allowed is the package's own ctypes.CDLL of libmtr_engine.so."""
     root = os.path.dirname(HERE)
-    for dirpath, _, files in os.walk(os.path.join(root, "meters.lv2_amd")):
-        for f in files:
-            if f.endswith((".py", ".c", ".h", ".hip", ".cc", "Makefile")):
-                txt = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "mtr_oracle" not in txt and "oracle/" not in txt and "_oracle" not in txt, (dirpath, f)
+    banned = (r"mtr_oracle", r"oracle/", r"_oracle", r"_ref\b", r"libmeters_ref", r"dlopen", r"dlsym")
+    for top in ("meters.lv2_amd", "include"):
+        for dirpath, dirs, files in os.walk(os.path.join(root, top)):
+            dirs[:] = [d for d in dirs if d not in ("lib", "lib_prof", "__pycache__")]      # built artefacts
+            for f in files:
+                if f.endswith((".py", ".c", ".h", ".hip", ".cc", "Makefile")):
+                    txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                    for word in banned:
+                        assert not re.search(word, txt), (dirpath, f, word)
+                    if f.endswith(".py"):
+                        assert txt.count("CDLL(") <= (2 if f == "engine.py" else 0), (dirpath, f)
 
 
 def test_setup_math_matches_reference_golden():

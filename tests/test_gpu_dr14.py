@@ -2,7 +2,7 @@
 (oracle mo_dr14_run, pinned to the LV2 plugin's behaviour by tests/test_lv2_dr14.py).
 
 The reference adds the squares of a 3 s window sequentially in f32; the kernel reduces in double, so a
-window's RMS can fall into the neighbouring 0.01 dB histogram bin: scores agree to +-0.02 dB, the window
+window's RMS can fall into the neighbouring 0.01 dB histogram bin: scores agree to +-0.01 dB (one bin; DR_TOL below), the window
 count and the peak are exact."""
 import ctypes as C
 
@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+DR_TOL = 0.01 + 1e-5      # the contract: one bin of the reference's 0.01 dB histogram (measured worst case in this file: 0.01)
 
 
 class Ports(C.Structure):
@@ -75,12 +76,12 @@ def test_dr14_batch_matches_the_restatement(M, oracle, fs, chn):
             assert got[s].block_count == want.block_count, (s, got[s].block_count, want.block_count)
             assert want.block_count >= 3 * 8                    # ten windows, at least one of them silent
             for c in range(chn):
-                assert abs(got[s].m_rms[c] - want.m_rms[c]) <= 0.02, (s, c, got[s].m_rms[c], want.m_rms[c])
+                assert abs(got[s].m_rms[c] - want.m_rms[c]) <= DR_TOL, (s, c, got[s].m_rms[c], want.m_rms[c])
                 # (the plugin's m_peak PORT shows the true-peak maximum; the engine's m_peak is the second-highest
                 # window peak that enters dr — checked through dr)
-                assert abs(got[s].dr[c] - want.dr[c]) <= 0.02, (s, c, got[s].dr[c], want.dr[c])
+                assert abs(got[s].dr[c] - want.dr[c]) <= DR_TOL, (s, c, got[s].dr[c], want.dr[c])
             if chn == 2:
-                assert abs(got[s].dr_total - want.dr_total) <= 0.02, s
+                assert abs(got[s].dr_total - want.dr_total) <= DR_TOL, s
         # reset_peaks
         e.dr14_reset()
         r = e.dr14()[0]
@@ -101,7 +102,7 @@ def test_dr14_batch_beside_the_other_meters(M, oracle):
         want = ref_dr14(oracle, x[s], fs, 2, [T])
         assert got[s].block_count == want.block_count and want.block_count >= 3 * 2
         for c in range(2):
-            assert abs(got[s].m_rms[c] - want.m_rms[c]) <= 0.02 or (got[s].m_rms[c] == want.m_rms[c])
+            assert abs(got[s].m_rms[c] - want.m_rms[c]) <= DR_TOL or (got[s].m_rms[c] == want.m_rms[c])
 
 
 def test_dr14_known_answers(M):

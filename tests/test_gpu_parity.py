@@ -9,8 +9,9 @@ Tolerances (stated once, used everywhere below):
   * fragment mean powers: 2e-5 relative (time-parallel summation order differs from the serial loop).
   * true peak: 2e-6 relative (FMA / accumulation order).
   * band levels of the 30-band bank: 1e-3 dB above -90 dB.
-  * integer histograms: identical except for those rare bin-edge flips; the number of differing
-    points is bounded explicitly.
+  * integer histograms: identical except for bin-edge flips (a fragment's loudness within ~1e-6 relative of a
+    0.1 dB edge: the time-parallel power sum differs from the serial one in the last bits): at most 2 points
+    per histogram may sit in the neighbouring bin, whatever the number of points.
 """
 import os
 import sys
@@ -49,10 +50,15 @@ def _check_ebu(got9, hist_got, want9, hist_want, cnt_want, frag_got=None, frag_w
     for h, w in zip(hist_got, hist_want):
         assert h.sum() == w.sum()
         moved = np.abs(h - w).sum() // 2
-        assert moved <= max(2, w.sum() // 100), moved
+        assert moved <= 2, moved             # a fragment power within ~1e-6 of a 0.1 dB bin edge; measured over this file: 0 or 1
     # I, thresholds, LRA: the contract
     assert abs(got9[4] - want9[4]) <= CONTRACT_DB and abs(got9[5] - want9[5]) <= CONTRACT_DB
-    assert abs(got9[6] - want9[6]) <= 0.1001 and abs(got9[7] - want9[7]) <= 0.1001
+    # LRA edges are bin indices of the 0.1 dB S histogram: identical histogram -> identical edges, bit for bit;
+    # a point that sits in the neighbouring bin can move an edge by that one bin
+    if np.array_equal(hist_got[1], hist_want[1]):
+        assert got9[6] == want9[6] and got9[7] == want9[7], (got9, want9)
+    else:
+        assert abs(got9[6] - want9[6]) <= 0.1001 and abs(got9[7] - want9[7]) <= 0.1001
     assert abs(got9[8] - want9[8]) <= CONTRACT_DB
     if frag_got is not None:
         assert frag_got.shape == frag_want.shape
