@@ -45,6 +45,32 @@ template <typename T> struct DevBuf {
 	void release () { if (p) (void) hipFree (p); p = nullptr; n = 0; }
 };
 
+// page-locked host memory (staging of the n_streams = 1 host path, plan uploads, result snapshots)
+template <typename T> struct PinBuf {
+	T*     p = nullptr;
+	size_t n = 0;
+	int reserve (size_t want) {
+		if (want <= n) return 0;
+		if (p) (void) hipHostFree (p);
+		p = nullptr; n = 0;
+		if (hipHostMalloc ((void**) &p, want * sizeof (T), hipHostMallocDefault) != hipSuccess) return -1;
+		n = want;
+		return 0;
+	}
+	void release () { if (p) (void) hipHostFree (p); p = nullptr; n = 0; }
+};
+
+// The tiling plan of a call lives in one of PLAN_SLOTS device buffers, uploaded from page-locked memory ON THE CALL'S
+// STREAM: a call whose (n_frames, fragment phase) differs from the previous one — every call, for 1024-frame blocks at
+// 48 kHz — never overwrites arrays that kernels of an earlier call may still be reading, and never blocks the host.
+constexpr int PLAN_SLOTS = 4;
+struct PlanSlot {
+	DevBuf<uint32_t> dev;       // [tile_start (n_tiles + 1) | seg_tile (n_segs + 1) | frag_tile (n_frag + 1)]
+	PinBuf<uint32_t> pin;
+	hipEvent_t       done = nullptr;   // recorded behind the last kernel that reads `dev`
+	bool             pending = false;
+};
+
 struct Plan {
 	uint64_t n_frames = 0;
 	uint32_t frcnt_in = 0;      // frames left in the open fragment when the call starts
@@ -70,7 +96,20 @@ struct mtr_engine {
 	DevBuf<float>    fir_hist[2];   // ping-pong 47-frame history
 	int              hist_cur = 0;
 	DevBuf<float>    scan_m, bin_power, tile_power, frag_power, stage;
-	DevBuf<uint32_t> tile_start, seg_tile, frag_tile;
+	PlanSlot         plan_slot[PLAN_SLOTS];
+	int              plan_cur = 0;
+	const uint32_t*  tile_start = nullptr;   // into plan_slot[plan_cur].dev
+	const uint32_t*  seg_tile = nullptr;
+	const uint32_t*  frag_tile = nullptr;
+	// n_streams = 1 host path (the shape of an LV2 run ()): own stream, page-locked staging, and ONE synchronisation per
+	// block — the state (and the bank's levels) come back with the same wait and serve the result getters
+	hipStream_t      own_stream = nullptr;
+	PinBuf<float>    pin_in;
+	PinBuf<mtr_stream_state> pin_state;
+	PinBuf<float>    pin_bank;               // [2][30] val, max
+	bool             snap_valid = false;
+	bool             queued = false;         // something has been launched on last_stream
+	hipEvent_t       xs_event = nullptr;     // orders a new stream behind the previous one
 	DevBuf<double>   bank_coef, bank_z;
 	DevBuf<float>    bank_val, bank_max;
 	DevBuf<int32_t>  bank_ac;
@@ -322,8 +361,10 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 			rc = fail (MTR_ERR_HIP, "hipMemcpy bank_coef");
 	}
 	if (rc != MTR_OK) { mtr_engine_destroy (e); return rc; }
+	rc = mtr_engine_reset (e);
+	if (rc != MTR_OK) { mtr_engine_destroy (e); return rc; }     // never an error code together with a live handle
 	*out = e;
-	return mtr_engine_reset (e);
+	return MTR_OK;
 }
 
 void mtr_engine_destroy (mtr_engine* e)
@@ -334,7 +375,11 @@ void mtr_engine_destroy (mtr_engine* e)
 	for (hipEvent_t ev : e->ev) (void) hipEventDestroy (ev);
 	e->state.release (); e->hist.release (); e->fir_hist[0].release (); e->fir_hist[1].release ();
 	e->scan_m.release (); e->bin_power.release (); e->tile_power.release (); e->frag_power.release ();
-	e->stage.release (); e->tile_start.release (); e->seg_tile.release (); e->frag_tile.release ();
+	e->stage.release ();
+	for (PlanSlot& ps : e->plan_slot) { ps.dev.release (); ps.pin.release (); if (ps.done) (void) hipEventDestroy (ps.done); }
+	e->pin_in.release (); e->pin_state.release (); e->pin_bank.release ();
+	if (e->own_stream) (void) hipStreamDestroy (e->own_stream);
+	if (e->xs_event) (void) hipEventDestroy (e->xs_event);
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
 	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release (); e->mfma_a.release (); e->m16_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
@@ -346,6 +391,7 @@ void mtr_engine_destroy (mtr_engine* e)
 int mtr_engine_reset (mtr_engine* e)
 {
 	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	e->snap_valid = false;
 	HIPCHK (hipSetDevice (e->cfg.device));
 	hipStream_t st = e->last_stream;
 	int rc = state_init (e, MTR_INIT_ALL, st);
@@ -372,6 +418,7 @@ int mtr_engine_reset (mtr_engine* e)
 int mtr_engine_kmeter_reset (mtr_engine* e)
 {
 	if (!e || !(e->cfg.meters & MTR_METER_KMETER)) return fail (MTR_ERR_ARG, "no KMETER in this engine");
+	e->snap_valid = false;
 	HIPCHK (hipSetDevice (e->cfg.device));
 	const size_t n = (size_t) e->cfg.n_streams * 2;
 	if (e->km_state.reserve (n)) return fail (MTR_ERR_NOMEM, "hipMalloc KMETER state");
@@ -397,6 +444,7 @@ int mtr_engine_kmeter_read (mtr_engine* e, uint32_t first, uint32_t count, float
 int mtr_engine_dr14_reset (mtr_engine* e)
 {
 	if (!e || !(e->cfg.meters & MTR_METER_DR14)) return fail (MTR_ERR_ARG, "no DR14 in this engine");
+	e->snap_valid = false;
 	HIPCHK (hipSetDevice (e->cfg.device));
 	const uint32_t S = e->cfg.n_streams;
 	if (e->dr_state.reserve (S) || e->dr_hist.reserve ((size_t) S * e->cfg.n_channels * MTR_DR_HISTBINS))
@@ -446,6 +494,7 @@ int mtr_engine_dr14_results (mtr_engine* e, uint32_t first, uint32_t count, mtr_
 int mtr_engine_intstat_reset (mtr_engine* e)
 {
 	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	e->snap_valid = false;
 	HIPCHK (hipSetDevice (e->cfg.device));
 	const uint32_t S = e->cfg.n_streams;
 	HIPCHK (hipStreamSynchronize (e->last_stream));
@@ -506,12 +555,14 @@ int mtr_engine_integr_pause (mtr_engine* e) { if (!e) return fail (MTR_ERR_ARG, 
 int mtr_engine_integr_reset (mtr_engine* e)
 {
 	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	e->snap_valid = false;
 	HIPCHK (hipSetDevice (e->cfg.device));
 	return state_init (e, MTR_INIT_INTEGR, e->last_stream);
 }
 int mtr_engine_truepeak_reset (mtr_engine* e)
 {
 	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	e->snap_valid = false;
 	HIPCHK (hipSetDevice (e->cfg.device));
 	return state_init (e, MTR_INIT_TP, e->last_stream);
 }
@@ -528,19 +579,19 @@ int mtr_engine_spectr_set_speed (mtr_engine* e, float v)
 int mtr_engine_spectr_reset_peak (mtr_engine* e)
 {
 	if (!e || !(e->cfg.meters & MTR_METER_SPECTR30)) return fail (MTR_ERR_ARG, "no SPECTR30 in this engine");
+	e->snap_valid = false;
 	HIPCHK (hipSetDevice (e->cfg.device));
 	HIPCHK (hipMemsetAsync (e->bank_max.p, 0, e->bank_max.n * sizeof (float), e->last_stream));
 	return MTR_OK;
 }
 
 // Tiling plan for a call of n_frames starting with `frcnt` frames left in the open fragment.
-static int build_plan (mtr_engine* e, uint64_t N)
+static int build_plan (mtr_engine* e, uint64_t N, hipStream_t st)
 {
 	Plan& pl = e->plan;
 	if (pl.valid && pl.n_frames == N && pl.frcnt_in == e->frcnt) return MTR_OK;
 	pl.valid = false;
 	const uint32_t LT = 64u * (uint32_t) e->run;
-	if (N >= 0xFFFFFFFFull) return fail (MTR_ERR_ARG, "n_frames per call must be < 2^32 - 1");
 
 	std::vector<uint32_t> ts, ft;
 	ts.reserve ((size_t) (N / LT + N / e->fragm + 4));
@@ -576,14 +627,22 @@ static int build_plan (mtr_engine* e, uint64_t N)
 	for (uint32_t q = 1; q < n_segs; ++q)
 		if ((uint64_t) ts[sg[q]] < (uint64_t) warm_tiles * LT) return fail (MTR_ERR_ARG, "internal: segment shorter than its warm-up");
 
-	if (e->tile_start.reserve (ts.size ()) || e->seg_tile.reserve (sg.size ()) || e->frag_tile.reserve (ft.size ())
-	    || e->tile_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_tiles, 1))
+	if (e->tile_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_tiles, 1))
 	    || e->frag_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_frag, 1)))
 		return fail (MTR_ERR_NOMEM, "hipMalloc plan buffers");
-	// plain synchronous copies: the plan is rebuilt only when (n_frames, fragment phase) changes
-	HIPCHK (hipMemcpy (e->tile_start.p, ts.data (), ts.size () * 4, hipMemcpyHostToDevice));
-	HIPCHK (hipMemcpy (e->seg_tile.p, sg.data (), sg.size () * 4, hipMemcpyHostToDevice));
-	HIPCHK (hipMemcpy (e->frag_tile.p, ft.data (), ft.size () * 4, hipMemcpyHostToDevice));
+	// the next slot of the ring; its previous contents were last read PLAN_SLOTS plans ago
+	const int slot = (e->plan_cur + 1) % PLAN_SLOTS;
+	PlanSlot& ps = e->plan_slot[slot];
+	if (ps.pending) { HIPCHK (hipEventSynchronize (ps.done)); ps.pending = false; }
+	const size_t words = ts.size () + sg.size () + ft.size ();
+	if (ps.dev.reserve (words) || ps.pin.reserve (words)) return fail (MTR_ERR_NOMEM, "plan slot");
+	if (!ps.done) HIPCHK (hipEventCreateWithFlags (&ps.done, hipEventDisableTiming));
+	memcpy (ps.pin.p, ts.data (), ts.size () * 4);
+	memcpy (ps.pin.p + ts.size (), sg.data (), sg.size () * 4);
+	memcpy (ps.pin.p + ts.size () + sg.size (), ft.data (), ft.size () * 4);
+	HIPCHK (hipMemcpyAsync (ps.dev.p, ps.pin.p, words * 4, hipMemcpyHostToDevice, st));
+	e->plan_cur = slot;
+	e->tile_start = ps.dev.p; e->seg_tile = ps.dev.p + ts.size (); e->frag_tile = ps.dev.p + ts.size () + sg.size ();
 
 	pl.n_frames = N; pl.frcnt_in = e->frcnt; pl.frcnt_out = left;
 	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail;
@@ -616,7 +675,23 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (stride < n_frames) return fail (MTR_ERR_ARG, "stream_stride_frames < n_frames");
 	HIPCHK (hipSetDevice (e->cfg.device));
 	hipStream_t st = (hipStream_t) hip_stream;
+	// every per-meter limit is checked before anything is launched or any host-side counter moves: a call that
+	// returns an error has not advanced the engine
+	if ((e->cfg.meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && n_frames >= 0x7fffffffull)
+		return fail (MTR_ERR_ARG, "BITSTATS / SIGDIST: n_frames per call must be < 2^31 - 1");
+	if ((e->cfg.meters & MTR_METER_KMETER) && n_frames >= 0x7fffffffull)
+		return fail (MTR_ERR_ARG, "KMETER: n_frames per call must be < 2^31 - 1 (the reference's int n)");
+	if ((e->cfg.meters & (MTR_METER_EBU | MTR_METER_TRUEPEAK)) && n_frames >= 0xFFFFFFFFull)
+		return fail (MTR_ERR_ARG, "n_frames per call must be < 2^32 - 1");
+	if (st != e->last_stream && e->queued) {
+		// the caller moved to another stream: order it behind what the previous one still has to do
+		if (!e->xs_event) HIPCHK (hipEventCreateWithFlags (&e->xs_event, hipEventDisableTiming));
+		HIPCHK (hipEventRecord (e->xs_event, e->last_stream));
+		HIPCHK (hipStreamWaitEvent (st, e->xs_event, 0));
+	}
 	e->last_stream = st;
+	e->queued = true;
+	e->snap_valid = false;
 	const uint32_t S = e->cfg.n_streams;
 	const bool ebu = e->cfg.meters & MTR_METER_EBU, tp = e->cfg.meters & MTR_METER_TRUEPEAK;
 	const bool bank = e->cfg.meters & MTR_METER_SPECTR30;
@@ -626,13 +701,13 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (tm) { hipEvent_t v = next_event (e, ev0); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 	if (ebu || tp) {
-		int rc = build_plan (e, n_frames);
+		int rc = build_plan (e, n_frames, st);
 		if (rc) return rc;
 		const Plan& pl = e->plan;
 		mtr_fused_args fa;
 		fa.audio = d_audio; fa.stride = stride;
 		fa.hist = e->fir_hist[e->hist_cur].p;
-		fa.tile_start = e->tile_start.p; fa.seg_tile = e->seg_tile.p; fa.scan_m = e->scan_m.p;
+		fa.tile_start = e->tile_start; fa.seg_tile = e->seg_tile; fa.scan_m = e->scan_m.p;
 		fa.state = e->state.p; fa.tile_power = e->tile_power.p;
 		fa.n_streams = S; fa.n_segs = pl.n_segs; fa.n_tiles = pl.n_tiles;
 		fa.warm_tiles = (uint32_t) std::ceil (MTR_WARM_SEC * e->cfg.sample_rate / (float) (64 * e->run));
@@ -656,12 +731,17 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 
 		mtr_gate_args ga;
 		ga.state = e->state.p; ga.hist = e->hist.p; ga.tile_power = e->tile_power.p;
-		ga.frag_tile = e->frag_tile.p; ga.frag_power = e->frag_power.p; ga.bin_power = e->bin_power.p;
+		ga.frag_tile = e->frag_tile; ga.frag_power = e->frag_power.p; ga.bin_power = e->bin_power.p;
 		ga.n_streams = S; ga.n_tiles = ebu ? pl.n_tiles : 0; ga.n_frag = ebu ? pl.n_frag : 0;
 		ga.tail_tile = ebu ? pl.tail_tile : 0;
 		ga.fragm = (float) e->fragm; ga.integr = e->integr ? 1 : 0;
 		ga.max_scratch = e->gate_max.p;
 		if (mtr_launch_gate (ga, st)) return fail (MTR_ERR_HIP, "k_gate launch");
+		{
+			PlanSlot& ps = e->plan_slot[e->plan_cur];                 // k_gate is the plan's last reader
+			HIPCHK (hipEventRecord (ps.done, st));
+			ps.pending = true;
+		}
 		e->last_n_frag = ga.n_frag;
 		e->frcnt = pl.frcnt_out;
 	} else if (tm) {
@@ -676,10 +756,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ba.n_streams = S; ba.n_channels = e->cfg.n_channels; ba.omega = e->omega;
 		if (mtr_launch_bank (ba, st)) return fail (MTR_ERR_HIP, "k_bank launch");
 	}
-	// the integer tables are int32 (as the reference's, which stops counting at 2^31 - 1 samples); the
-	// kernels index a call's samples with 32 bits
-	if ((e->cfg.meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && n_frames >= 0x7fffffffull)
-		return fail (MTR_ERR_ARG, "BITSTATS / SIGDIST: n_frames per call must be < 2^31 - 1");
+	// (the integer tables are int32, as the reference's, which stops counting at 2^31 - 1 samples; the kernels index
+	// a call's samples with 32 bits: checked on entry)
 	if (e->cfg.meters & MTR_METER_BITSTATS)
 		if (mtr_launch_bitstats (d_audio, stride, n_frames, e->bim.p, S, st)) return fail (MTR_ERR_HIP, "k_bitstats launch");
 	if (e->cfg.meters & MTR_METER_SIGDIST)
@@ -700,7 +778,6 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		e->dr_scnt = tot % da.window;
 	}
 	if (e->cfg.meters & MTR_METER_KMETER) {
-		if (n_frames >= 0x7fffffffull) return fail (MTR_ERR_ARG, "KMETER: n_frames per call must be < 2^31 - 1 (the reference's int n)");
 		mtr_kmeter_args ka;
 		ka.audio = d_audio; ka.stride = stride; ka.n_groups = n_frames / 4;
 		ka.n_streams = S; ka.n_channels = e->cfg.n_channels;
@@ -743,6 +820,13 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	return MTR_OK;
 }
 
+static int host_stream (mtr_engine* e, hipStream_t* st)
+{
+	if (!e->own_stream) HIPCHK (hipStreamCreateWithFlags (&e->own_stream, hipStreamNonBlocking));
+	*st = e->own_stream;
+	return MTR_OK;
+}
+
 int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_frames, uint64_t stride)
 {
 	if (!e || !h_audio) return fail (MTR_ERR_ARG, "mtr_engine_process_host: null argument");
@@ -751,10 +835,12 @@ int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_fra
 	HIPCHK (hipSetDevice (e->cfg.device));
 	const size_t C = e->cfg.n_channels;
 	const size_t total = (size_t) e->cfg.n_streams * n_frames * C;
+	hipStream_t st;
+	int rc = host_stream (e, &st);
+	if (rc) return rc;
+	// the staging buffer may still be read by the previous call (on whatever stream that ran)
+	HIPCHK (hipStreamSynchronize (e->last_stream));
 	if (e->stage.reserve (total)) return fail (MTR_ERR_NOMEM, "hipMalloc staging buffer");
-	hipStream_t st = e->last_stream;
-	// the staging buffer may still be read by the previous call
-	HIPCHK (hipStreamSynchronize (st));
 	HIPCHK (hipMemcpy2DAsync (e->stage.p, n_frames * C * sizeof (float), h_audio, stride * C * sizeof (float),
 	                          n_frames * C * sizeof (float), e->cfg.n_streams, hipMemcpyHostToDevice, st));
 	// The source is pageable caller memory and the copy is truly asynchronous: the caller may free
@@ -763,6 +849,8 @@ int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_fra
 	return mtr_engine_process_device (e, e->stage.p, n_frames, n_frames, st);
 }
 
+// One LV2 block: interleave into page-locked memory, one H2D copy, the kernels, one D2H copy of the stream's state
+// (and the bank's levels), ONE wait.  No allocation after the first block of a given size.
 int mtr_engine_process_planar_host (mtr_engine* e, const float* const* ch, uint32_t n_frames)
 {
 	if (!e || !ch || !ch[0]) return fail (MTR_ERR_ARG, "mtr_engine_process_planar_host: null argument");
@@ -770,13 +858,30 @@ int mtr_engine_process_planar_host (mtr_engine* e, const float* const* ch, uint3
 	if (n_frames == 0) return MTR_OK;
 	const uint32_t C = e->cfg.n_channels;
 	if (C == 2 && !ch[1]) return fail (MTR_ERR_ARG, "missing right channel");
-	std::vector<float> il ((size_t) n_frames * C);
-	if (C == 2) for (uint32_t i = 0; i < n_frames; ++i) { il[2 * i] = ch[0][i]; il[2 * i + 1] = ch[1][i]; }
-	else        memcpy (il.data (), ch[0], (size_t) n_frames * sizeof (float));
-	int rc = mtr_engine_process_host (e, il.data (), n_frames, n_frames);
+	HIPCHK (hipSetDevice (e->cfg.device));
+	hipStream_t st;
+	int rc = host_stream (e, &st);
 	if (rc) return rc;
-	// `il` dies with this frame: make sure the copy has been consumed
-	HIPCHK (hipStreamSynchronize (e->last_stream));
+	if (e->last_stream != st) HIPCHK (hipStreamSynchronize (e->last_stream));   // resets queued before the first block
+	const size_t total = (size_t) n_frames * C;
+	if (e->pin_in.n < total || e->stage.n < total) {
+		HIPCHK (hipStreamSynchronize (st));
+		if (e->pin_in.reserve (total) || e->stage.reserve (total)) return fail (MTR_ERR_NOMEM, "staging buffers");
+	}
+	if (e->pin_state.reserve (1) || e->pin_bank.reserve (2 * MTR_NBANDS)) return fail (MTR_ERR_NOMEM, "hipHostMalloc snapshot");
+	float* const il = e->pin_in.p;                 // free: the previous block ended with a wait
+	if (C == 2) for (uint32_t i = 0; i < n_frames; ++i) { il[2 * i] = ch[0][i]; il[2 * i + 1] = ch[1][i]; }
+	else        memcpy (il, ch[0], (size_t) n_frames * sizeof (float));
+	HIPCHK (hipMemcpyAsync (e->stage.p, il, total * sizeof (float), hipMemcpyHostToDevice, st));
+	rc = mtr_engine_process_device (e, e->stage.p, n_frames, n_frames, st);
+	if (rc) return rc;
+	HIPCHK (hipMemcpyAsync (e->pin_state.p, e->state.p, sizeof (mtr_stream_state), hipMemcpyDeviceToHost, st));
+	if (e->cfg.meters & MTR_METER_SPECTR30) {
+		HIPCHK (hipMemcpyAsync (e->pin_bank.p, e->bank_val.p, MTR_NBANDS * sizeof (float), hipMemcpyDeviceToHost, st));
+		HIPCHK (hipMemcpyAsync (e->pin_bank.p + MTR_NBANDS, e->bank_max.p, MTR_NBANDS * sizeof (float), hipMemcpyDeviceToHost, st));
+	}
+	HIPCHK (hipStreamSynchronize (st));
+	e->snap_valid = true;
 	return MTR_OK;
 }
 
@@ -801,10 +906,14 @@ int mtr_engine_results (mtr_engine* e, uint32_t first, uint32_t count, mtr_strea
 	if (rc) return rc;
 	if (!out) return fail (MTR_ERR_ARG, "null output");
 	if (count == 0) return MTR_OK;
-	rc = mtr_engine_sync (e);
-	if (rc) return rc;
 	std::vector<mtr_stream_state> h (count);
-	HIPCHK (hipMemcpy (h.data (), e->state.p + first, count * sizeof (mtr_stream_state), hipMemcpyDeviceToHost));
+	if (e->snap_valid && e->cfg.n_streams == 1) {
+		h[0] = e->pin_state.p[0];                                     // came back with the block's own wait
+	} else {
+		rc = mtr_engine_sync (e);
+		if (rc) return rc;
+		HIPCHK (hipMemcpy (h.data (), e->state.p + first, count * sizeof (mtr_stream_state), hipMemcpyDeviceToHost));
+	}
 	for (uint32_t i = 0; i < count; ++i) {
 		const mtr_stream_state& s = h[i];
 		mtr_stream_result& r = out[i];
@@ -857,12 +966,17 @@ int mtr_engine_spectrum (mtr_engine* e, uint32_t first, uint32_t count, float* v
 	if (rc) return rc;
 	if (!(e->cfg.meters & MTR_METER_SPECTR30)) return fail (MTR_ERR_ARG, "no SPECTR30 in this engine");
 	if (count == 0) return MTR_OK;
-	rc = mtr_engine_sync (e);
-	if (rc) return rc;
 	const size_t n = (size_t) count * MTR_NBANDS;
 	std::vector<float> v (n), m (n);
-	HIPCHK (hipMemcpy (v.data (), e->bank_val.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
-	HIPCHK (hipMemcpy (m.data (), e->bank_max.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
+	if (e->snap_valid && e->cfg.n_streams == 1) {
+		memcpy (v.data (), e->pin_bank.p, n * 4);                     // came back with the block's own wait
+		memcpy (m.data (), e->pin_bank.p + MTR_NBANDS, n * 4);
+	} else {
+		rc = mtr_engine_sync (e);
+		if (rc) return rc;
+		HIPCHK (hipMemcpy (v.data (), e->bank_val.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
+		HIPCHK (hipMemcpy (m.data (), e->bank_max.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
+	}
 	for (size_t i = 0; i < n; ++i) {
 		// spectrumlv2.c:240-247.  The stored val carries the +1e-20f of :237; above the -100 dB floor
 		// (val > 5e-11) that addition does not change the float, so the port value is unaffected.
