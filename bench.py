@@ -7,15 +7,18 @@ over one batch of synthetic 48 kHz stereo audio that is already resident in HBM:
 configs[4]; the metric is quoted on batched EBU R128 + true-peak).  Streams are independent, so
 ranks shard them with no data-path collective (weak scaling: per-GPU work is fixed); the only
 RCCL traffic is the final all-reduce of the two 751-bin loudness histograms (sum) and the
-peak / max-loudness values (max), done once per step.
+peak / max-loudness values (max), done once per step by mtr_engine_reduce() — RCCL inside the C ABI
+(torch.distributed only ships the 128-byte communicator id and provides the barrier).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  `value` counts channel-samples/s (2 per stereo frame), whole job.
-`roofline` prices the dominant kernel (k_fused) at 8 algorithmic bytes per stereo frame (one read
-of the input) against the 8 TB/s HBM peak, with the kernel's duration measured by
-HIP events on the launching stream inside the timed steps.  `cpu_baseline` times the reference's
+`roofline` prices the dominant kernel (k_kwtp16, mtr_fused4.hip: K-weighting + the 4x interpolator on the
+matrix pipe at f32 grade) at 8 algorithmic bytes per stereo frame (one read of the input)
+against the 8 TB/s HBM peak, with the kernel's duration measured by HIP events on the launching stream
+inside the timed steps.  `extra.configs` carries every BASELINE config at its stated size, `extra.lv2_run_latency`
+the per-block cost of the LV2 plugins.  `cpu_baseline` times the reference's
 own DSP objects (oracle/_ref, kind "reference") — or the repo's restatement (kind "port") where
 that build is absent — on a bounded sample of the same buffers on the host cores.
 """
@@ -76,6 +79,30 @@ def cpu_baseline(host_audio, fs, budget_s=12.0):
     return out
 
 
+def kernel_sha():
+    """Hash of the sources of the dominant kernel: the committed PMC traffic figure is valid for exactly this code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mtr_fused4.hip", "mtr_mfma16_fir.h", "mtr_wave.h"):
+        h.update(open(os.path.join(ROOT, "meters.lv2_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(meters, S, T, layout):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md):
+    the counters cannot be read from inside this process, so the figure is reported only for the very workload AND the
+    very kernel sources it was measured on (profiles/r02_traffic.json carries their hash); otherwise null."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        w = tj["workload"]
+        if (meters, S, T, layout) == (w["meters"], w["streams_per_gpu"], w["frames_per_stream"], w["layout"]) \
+                and tj["kernel_sha16"] == kernel_sha():
+            return tj["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,7 +114,9 @@ def main():
                                                            "bitstats", "sigdist", "tpb", "dr14", "kmeter"])
     ap.add_argument("--run", type=int, default=0, help="frames per lane run (0 = engine default)")
     ap.add_argument("--segments", type=int, default=0)
-    ap.add_argument("--layout", type=int, default=0, help="0 auto, 1 wave per segment, 2/3 wave-specialised, 4 K-weighting only, 5 matrix-pipe interpolator")
+    ap.add_argument("--layout", type=int, default=0, help="0 auto (6 with true peak, 4 without), 1 wave per segment, 2/3 exact-f32 VALU interpolator, "
+                                                          "4 K-weighting only, 5 matrix pipe with f16 taps (round 1), 6 matrix pipe at f32 grade")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.lv2_run_latency (N = 1 only anyway)")
     ap.add_argument("--fir", type=int, default=0, help="0 auto (mirror-symmetric form), 1 dense 3x48 taps")
     ap.add_argument("--prune", type=int, default=0, help="1 = exact true-peak pruning (identical result, data-dependent speed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,6 +173,8 @@ def main():
     eng = M.Engine(S, fs, meters, n_channels=1 if mono else 2, device=local, tune_run=args.run,
                    tune_segments=args.segments, tune_layout=args.layout, tune_fir=args.fir, tune_prune=args.prune)
     eng.integr_start()
+    # the job's communicator: RCCL behind the C ABI; on a shared-GPU rehearsal (gloo) the torch fallback reduces
+    comm = None if shared else mdist.make_comm(rank, world, local)
 
     def step():
         if mono:
@@ -151,8 +182,11 @@ def main():
             return
         eng.process_device(buf.data_ptr(), T, T, stream)
         if meters & (M.METER_EBU | M.METER_TRUEPEAK):
-            eng.aggregate_device(agg_hist.data_ptr(), agg_max.data_ptr(), stream)
-            mdist.all_reduce_aggregate(agg_hist, agg_max)   # the only collective of the job (RCCL)
+            if comm is not None:
+                eng.reduce(comm, agg_hist.data_ptr(), agg_max.data_ptr(), stream)   # the only collective of the job (RCCL)
+            else:
+                eng.aggregate_device(agg_hist.data_ptr(), agg_max.data_ptr(), stream)
+                mdist.all_reduce_aggregate(agg_hist, agg_max)
 
     for _ in range(args.warmup):
         step()
@@ -195,38 +229,34 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream": T, "sample_rate": fs,
                        "frames_per_s": frames_job / dt, "parallelism": f"streams sharded x{world}"},
         }
+        layout = eng.layout()
         if tq["calls"] and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
             k_ms = tq["ms_fused"] / tq["calls"]
             achieved = S * T * BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
-            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), valid for the
-            # profiled workload only; the counters cannot be read from inside this process
-            traffic = None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                w = tj["workload"]
-                if (args.meters, S, T) == (w["meters"], w["streams_per_gpu"], w["frames_per_stream"]):
-                    traffic = tj["traffic_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
-                pass
-            # the roofline that actually binds: packed fp32 VALU. Useful work = 120 (mirror-symmetric
-            # interpolator) + 23 (K-weighting, two passes) packed operations per stereo frame
-            valu_ops = 143.0 * S * T / (k_ms * 1e-3) * 2 * 2        # flop/s: 2 lanes x FMA
+            kname = {6: "k_kwtp16", 5: "k_kwtp", 4: "k_kw"}.get(layout, "k_fused2")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_fused2", "kernel_ms": k_ms, "gate_ms": tq["ms_gate"] / tq["calls"],
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(args.meters, S, T, layout),
+                               "kernel": kname, "kernel_ms": k_ms, "gate_ms": tq["ms_gate"] / tq["calls"],
                                "algorithmic_bytes_per_launch": S * T * BYTES_PER_FRAME}
-            if args.layout == 5:
-                out["roofline"]["kernel"] = "k_kwtp"
-                out["roofline"]["note"] = ("OPTIONAL layout 5: interpolator on the matrix pipe with f16-split samples "
-                                           "(peaks within 0.0056 dB of the f32 interpolator, not bit-identical)")
+            if layout == 6:
+                # what binds: issue slots of the SIMDs.  Per stereo frame the kernel issues 18 x 2 / 256 MFMAs
+                # (16x16x32 f16, 16 cycles of the matrix pipe each) and ~37 VALU instructions (~23 without the K-filter);
+                # packed-f32 VALU work and MFMAs do not overlap on a SIMD (tools/coissue.hip), so the two add up.
+                mfma_flop = 2.0 * 16 * 16 * 32 * (36.0 / 256.0) * S * T / (k_ms * 1e-3)
+                out["roofline"]["binding_roofline"] = {
+                    "bound": "SIMD issue: f16 MFMA (3 partial products) + packed-f32 VALU, not overlapping",
+                    "mfma_achieved_tflops": mfma_flop / 1e12, "mfma_peak_tflops": 2500.0, "mfma_frac": mfma_flop / 2.5e15}
+                out["roofline"]["note"] = ("interpolator on the matrix pipe at f32 grade (samples and taps as two f16 halves, three "
+                                           "partial products, f32 accumulation): same 2e-6 parity bound as the exact-f32 VALU path")
+                out["dtype"] = "f32 (K-filter: packed f32 VALU; interpolator: f16x2-split samples x f16x2-split taps on MFMA, f32 accumulate)"
+            elif layout == 5:
+                out["roofline"]["note"] = ("layout 5 (round 1): matrix pipe with single-f16 taps, peaks within 0.0056 dB of the f32 "
+                                           "interpolator — narrower than the reference, kept for comparison only")
                 out["dtype"] = "f32 K-filter; f16x2-split samples, f16 taps, f32 accumulation in the interpolator"
-            elif meters & M.METER_TRUEPEAK:
+            elif layout in (1, 2, 3) and meters & M.METER_TRUEPEAK:
+                valu_ops = 143.0 * S * T / (k_ms * 1e-3) * 2 * 2        # flop/s: 2 lanes x FMA
                 out["roofline"]["binding_roofline"] = {"bound": "fp32 VALU (v_pk_fma_f32)", "achieved_tflops": valu_ops / 1e12,
                                                        "peak_tflops": 157.3, "frac": valu_ops / 157.3e12}
-                out["roofline"]["note"] = ("fp32-VALU bound, not HBM bound: the 4x interpolator alone needs 120 packed "
-                                           "VALU ops per 8-byte frame (SURVEY.md 8d: ceiling ~27% of HBM peak)")
-            elif args.layout in (0, 4):
-                out["roofline"]["kernel"] = "k_kw"              # K-weighting only: the HBM-bound kernel (mtr_kw.hip)
         elif tq["calls"] and tq["ms_bank"] > 0:
             k_ms = tq["ms_bank"] / tq["calls"]
             achieved = S * T * BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
@@ -246,61 +276,78 @@ def main():
         if world == 1 and not args.no_cpu_baseline and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
             n = min(S, 256)
             out["cpu_baseline"] = cpu_baseline(buf[:n].cpu().numpy(), fs)
-        if world == 1 and not args.no_cpu_baseline and args.meters == "ebu+tp" and not args.prune:
-            # Reported NEXT TO the dense number, never instead of it: the same workload with exact peak
-            # pruning (bit-identical results, tests/test_gpu_layouts.py; speed depends on the programme).
-            with M.Engine(S, fs, meters, device=local, tune_run=args.run, tune_segments=args.segments,
-                          tune_layout=args.layout, tune_fir=args.fir, tune_prune=1) as pe:
-                pe.integr_start()
-                pe.process_device(buf.data_ptr(), T, T, stream)
-                torch.cuda.synchronize()
-                pe.timing_enable(True)
-                for _ in range(max(args.steps // 2, 1)):
-                    pe.process_device(buf.data_ptr(), T, T, stream)
-                torch.cuda.synchronize()
-                pq = pe.timing_query()
-                pc, pk = pe.prune_stats()
-                p_ms = pq["ms_fused"] / max(pq["calls"], 1)
-                same = bool(np.array_equal(pe.truepeak(), eng.truepeak()))
-            out["exact_pruning"] = {"kernel_ms": p_ms, "frac": S * T * BYTES_PER_FRAME / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "tiles_skipped_frac": pk / max(pc, 1), "peaks_identical_to_dense": same,
-                                    "note": "optional (tune_prune=1); not part of `value`"}
-        if world == 1 and not args.no_cpu_baseline and args.meters == "ebu+tp" and not args.prune and args.layout != 5:
-            # Also next to — not instead of — `value`: the same workload through layout 5 (mtr_fused3.hip), whose
-            # true peaks carry the rounding of f16 taps: at most 0.0056 dB from the f32 interpolator.
-            with M.Engine(S, fs, meters, device=local, tune_segments=args.segments, tune_layout=5) as me:
-                me.integr_start()
-                me.process_device(buf.data_ptr(), T, T, stream)
-                torch.cuda.synchronize()
-                me.timing_enable(True)
-                for _ in range(max(args.steps // 2, 1)):
-                    me.process_device(buf.data_ptr(), T, T, stream)
-                torch.cuda.synchronize()
-                mq = me.timing_query()
-                m_ms = mq["ms_fused"] / max(mq["calls"], 1)
-                a5, a3 = np.maximum(me.truepeak().astype(np.float64), 1e-30), np.maximum(eng.truepeak().astype(np.float64), 1e-30)
-                ddb = float(np.abs(20 * np.log10(a5 / a3)).max())
-                dlu = float(np.abs(me.out9()[:, 4].astype(np.float64) - eng.out9()[:, 4].astype(np.float64)).max())
-                m_peaks = me.truepeak()
-            with M.Engine(S, fs, meters, device=local, tune_segments=args.segments, tune_layout=5, tune_prune=1) as mp:
-                mp.integr_start()
-                mp.process_device(buf.data_ptr(), T, T, stream)
-                torch.cuda.synchronize()
-                mp.timing_enable(True)
-                for _ in range(max(args.steps // 2, 1)):
-                    mp.process_device(buf.data_ptr(), T, T, stream)
-                torch.cuda.synchronize()
-                mpq = mp.timing_query()
-                mp_ms = mpq["ms_fused"] / max(mpq["calls"], 1)
-                mc, mk = mp.prune_stats()
-                mp_same = bool(np.array_equal(mp.truepeak(), m_peaks))
-            out["matrix_pipe_interpolator"] = {
-                "kernel": "k_kwtp", "kernel_ms": m_ms, "frac": S * T * BYTES_PER_FRAME / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "max_abs_db_vs_f32_peaks": ddb, "bound_db": 0.0056, "integrated_lufs_max_abs_diff": dlu,
-                "with_exact_pruning": {"kernel_ms": mp_ms, "frac": S * T * BYTES_PER_FRAME / (mp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       "tiles_skipped_frac": mk / max(mc, 1), "peaks_identical_to_unpruned": mp_same},
-                "note": "optional (tune_layout=5): f16-split samples x f16 taps on v_mfma_f32_32x32x16_f16, f32 accumulation; "
-                        "within the +-0.01 dB parity tolerance but not bit-identical, so not part of `value`"}
+        headline = world == 1 and not args.no_cpu_baseline and not args.no_extra and args.meters == "ebu+tp" and not args.prune \
+            and args.layout == 0 and (S, T) == (8192, 480000)
+        if headline:
+            extra = {}
+            peaks = eng.truepeak()
+            o9 = eng.out9()
+
+            def timed(eS, eT, emeters, steps=3, **kw):
+                """ms per launch of the fused / gate / bank kernels for eS streams x eT frames of the same buffer."""
+                with M.Engine(eS, fs, emeters, device=local, **kw) as x:
+                    if emeters & M.METER_EBU:
+                        x.integr_start()
+                    x.process_device(buf.data_ptr(), eT, eT, stream)
+                    torch.cuda.synchronize()
+                    x.timing_enable(True)
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        x.process_device(buf.data_ptr(), eT, eT, stream)
+                    torch.cuda.synchronize()
+                    wall = 1e3 * (time.perf_counter() - t0) / steps
+                    q = x.timing_query()
+                    c = max(q["calls"], 1)
+                    keep = {"tp": x.truepeak() if emeters & M.METER_TRUEPEAK else None,
+                            "o9": x.out9() if emeters & M.METER_EBU else None, "prune": x.prune_stats(), "layout": x.layout()}
+                return q["ms_fused"] / c, q["ms_gate"] / c, q["ms_bank"] / c, wall, keep
+
+            def frac(eS, eT, ms):
+                return eS * eT * BYTES_PER_FRAME / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+            # Next to — never instead of — `value`: exact peak pruning (bit-identical peaks, data-dependent speed) and the
+            # exact-f32 VALU interpolator of round 1 (layout 3), whose peaks the matrix-pipe path must reproduce.
+            f, g, _, _, k = timed(S, T, meters, tune_prune=1)
+            extra["exact_pruning"] = {"kernel_ms": f, "frac": frac(S, T, f), "tiles_skipped_frac": k["prune"][1] / max(k["prune"][0], 1),
+                                      "peaks_identical_to_dense": bool(np.array_equal(k["tp"], peaks)),
+                                      "note": "optional (tune_prune=1); not part of `value`"}
+            f, g, _, _, k = timed(S, T, meters, tune_layout=3)
+            rel = np.abs(k["tp"].astype(np.float64) - peaks) / np.maximum(peaks.astype(np.float64), 1e-30)
+            extra["f32_valu_interpolator"] = {"kernel": "k_fused2", "kernel_ms": f, "frac": frac(S, T, f),
+                                              "max_rel_dev_of_default_peaks": float(rel.max()),
+                                              "max_abs_dev_integrated_lufs": float(np.abs(k["o9"][:, 4].astype(np.float64) - o9[:, 4]).max()),
+                                              "note": "layout 3: bit-for-bit an fmaf chain on the VALU (round 1's default)"}
+            # Every BASELINE config at its stated size (configs[0] is the CPU plumbing case: tests/test_lv2_plugin.py).
+            cfgs = {}
+            c1 = 3600 * 48000
+            f, g, _, w, _ = timed(1, c1, M.METER_EBU, steps=5)
+            cfgs["1: EBU R128, 1 stream x 3600 s"] = {"kernel": "k_kw", "kernel_ms": f, "gate_ms": g, "wall_ms": w, "frac": frac(1, c1, f),
+                                                      "whole_step_frac": frac(1, c1, w), "bound": "hbm"}
+            f, g, _, w, _ = timed(1, c1, meters, steps=5)
+            cfgs["1 + true peak: 1 stream x 3600 s"] = {"kernel": "k_kwtp16", "kernel_ms": f, "gate_ms": g, "wall_ms": w, "frac": frac(1, c1, f),
+                                                        "whole_step_frac": frac(1, c1, w), "bound": "SIMD issue (MFMA + VALU)"}
+            f, _, _, w, _ = timed(1024, 60 * 48000, M.METER_TRUEPEAK)
+            cfgs["2: 4x true peak, 1024 streams x 60 s"] = {"kernel": "k_kwtp16", "kernel_ms": f, "wall_ms": w, "frac": frac(1024, 60 * 48000, f),
+                                                          "bound": "SIMD issue (MFMA + VALU)"}
+            _, _, bk, w, _ = timed(4096, T, M.METER_SPECTR30, steps=2)
+            cfgs["3: 30-band bank, 4096 streams x 10 s"] = {"kernel": "k_bank", "kernel_ms": bk, "wall_ms": w, "frac": frac(4096, T, bk),
+                                                           "bound": "fp64 VALU (ceiling 4.2-5.0 % of HBM peak, SURVEY.md 8d)"}
+            f, g, bk, w, _ = timed(S, T, meters | M.METER_SPECTR30, steps=2)
+            cfgs["4: EBU + true peak + bank, 8192 streams x 10 s (one of 8 shards)"] = {
+                "kernel_ms": {"k_kwtp16": f, "k_gate": g, "k_bank": bk}, "wall_ms": w, "frac": frac(S, T, w),
+                "bound": "fp64 VALU (k_bank) + SIMD issue (k_kwtp16); the bank's second read of the audio is %.1f %% of the step" % (100 * (S * T * 8 / 5.0e12 * 1e3) / w)}
+            extra["configs"] = cfgs
+            try:
+                from _lv2host import Host
+                from _lv2lat import run_latency
+                host, lat = Host(), {}
+                for name in ("EBUr128", "dBTPstereo", "spectr30stereo"):
+                    lat[name] = {str(n): {k: round(v, 1) for k, v in run_latency(host, name, n, blocks=100, warm=10).items()}
+                                 for n in (64, 256, 1024, 8192)}
+                extra["lv2_run_latency"] = {"unit": "us per run() at 48 kHz, by block size (budget_us = the block's real time)", **lat}
+            except Exception as exc:                              # never let a context figure break the benchmark line
+                extra["lv2_run_latency"] = {"error": repr(exc)}
+            out["extra"] = extra
         out["programme"] = mdist.programme_summary(agg_hist, agg_max)
         if args.prune:
             c, k = eng.prune_stats()
@@ -309,6 +356,8 @@ def main():
                                     "NOT the default and not the dense headline number"}
         print(json.dumps(out), flush=True)
     eng.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -188,6 +188,21 @@ int  mtr_engine_kmeter_reset (mtr_engine* e);
  * buffers owned by the caller, so the host can all-reduce them across ranks (RCCL) in place.
  * No reference counterpart (the reference is single-instance). */
 int  mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, void* hip_stream);
+/* The job's ONE collective, RCCL inside: every rank's streams are independent, so the only
+ * exchange is the final reduction of the per-rank aggregates — sum of the two 751-bin histograms, max of the peaks.
+ *   rank 0:  mtr_comm_unique_id (id)                      -> ncclGetUniqueId; ship the 128 bytes to every rank
+ *   each:    mtr_comm_init (&c, rank, world, id, device)  -> ncclCommInitRank (collective: all ranks call it)
+ *   per job: mtr_engine_reduce (e, c, d_hist, d_max, st)  -> mtr_engine_aggregate_device on this rank's streams, then
+ *            ncclAllReduce (int32[1502], sum) and ncclAllReduce (float[4], max) in place on `st`;
+ *            mtr_hist_loudness () turns the summed histograms into the programme's loudness and range.
+ * world = 1 is valid (the reduction is the identity).  No reference counterpart (the reference is single-instance). */
+#define MTR_COMM_ID_BYTES 128
+typedef struct mtr_comm mtr_comm;
+int  mtr_comm_unique_id (void* id128);
+int  mtr_comm_init (mtr_comm** out, int rank, int world, const void* id128, int device);
+void mtr_comm_destroy (mtr_comm* c);
+int  mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max, void* hip_stream);
+
 /* Programme-level integrated loudness / range from (summed) histograms, exactly as
  * Ebu_r128_hist::calc_integ / calc_range do (ebu_r128_proc.cc:105-150). Host-side, pure C. */
 void mtr_hist_loudness (const int32_t* hist_M, const int32_t* hist_S,

@@ -5,6 +5,7 @@
 // independent waves when the batch is small) and launches the HIP kernels on the caller's
 // stream.  There is no CPU fallback anywhere in this file: without a HIP device create() fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -999,6 +1000,72 @@ int mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, v
 		return fail (MTR_ERR_NOMEM, "hipMalloc aggregate scratch");
 	if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, e->agg_hist.p, e->agg_max.p, d_hist, d_max, hip_stream))
 		return fail (MTR_ERR_HIP, "k_aggregate launch");
+	return MTR_OK;
+}
+
+// ---- the one collective of a multi-GPU job: RCCL behind the C ABI ---------------------------------------------------
+struct mtr_comm {
+	ncclComm_t comm = nullptr;
+	int rank = 0, world = 1, device = 0;
+};
+
+static int nccl_fail (const char* what, ncclResult_t r)
+{
+	char buf[256];
+	snprintf (buf, sizeof (buf), "%s: %s", what, ncclGetErrorString (r));
+	g_err = buf;
+	return MTR_ERR_HIP;
+}
+
+int mtr_comm_unique_id (void* id128)
+{
+	static_assert (sizeof (ncclUniqueId) == MTR_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+	if (!id128) return fail (MTR_ERR_ARG, "mtr_comm_unique_id: null argument");
+	ncclUniqueId id;
+	const ncclResult_t r = ncclGetUniqueId (&id);
+	if (r != ncclSuccess) return nccl_fail ("ncclGetUniqueId", r);
+	memcpy (id128, &id, sizeof (id));
+	return MTR_OK;
+}
+
+int mtr_comm_init (mtr_comm** out, int rank, int world, const void* id128, int device)
+{
+	if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return fail (MTR_ERR_ARG, "mtr_comm_init: bad argument");
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0) return fail (MTR_ERR_NODEVICE, "no HIP device");
+	if (device < 0 || device >= ndev) return fail (MTR_ERR_ARG, "device ordinal out of range");
+	HIPCHK (hipSetDevice (device));
+	mtr_comm* c = new (std::nothrow) mtr_comm ();
+	if (!c) return fail (MTR_ERR_NOMEM, "new mtr_comm");
+	c->rank = rank; c->world = world; c->device = device;
+	ncclUniqueId id;
+	memcpy (&id, id128, sizeof (id));
+	const ncclResult_t r = ncclCommInitRank (&c->comm, world, id, rank);
+	if (r != ncclSuccess) { delete c; return nccl_fail ("ncclCommInitRank", r); }
+	*out = c;
+	return MTR_OK;
+}
+
+void mtr_comm_destroy (mtr_comm* c)
+{
+	if (!c) return;
+	(void) hipSetDevice (c->device);
+	if (c->comm) (void) ncclCommDestroy (c->comm);
+	delete c;
+}
+
+int mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max, void* hip_stream)
+{
+	if (!e || !c || !d_hist || !d_max) return fail (MTR_ERR_ARG, "mtr_engine_reduce: null argument");
+	if (c->device != e->cfg.device) return fail (MTR_ERR_ARG, "mtr_engine_reduce: engine and communicator sit on different devices");
+	int rc = mtr_engine_aggregate_device (e, d_hist, d_max, hip_stream);
+	if (rc) return rc;
+	hipStream_t st = (hipStream_t) hip_stream;
+	ncclResult_t r = ncclAllReduce (d_hist, d_hist, 2 * MTR_HIST_LEN, ncclInt32, ncclSum, c->comm, st);
+	if (r != ncclSuccess) return nccl_fail ("ncclAllReduce (histograms)", r);
+	r = ncclAllReduce (d_max, d_max, 4, ncclFloat32, ncclMax, c->comm, st);
+	if (r != ncclSuccess) return nccl_fail ("ncclAllReduce (peaks)", r);
 	return MTR_OK;
 }
 

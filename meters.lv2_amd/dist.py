@@ -3,9 +3,12 @@
 Streams are independent, so rank r of W owns the block [first, first+count) and no audio ever
 crosses xGMI.  The only exchange is the final reduction of the per-rank aggregates that
 mtr_engine_aggregate_device() leaves in device memory: int32[2][751] loudness histograms (sum)
-and float[4] = {tp_L, tp_R, maxloudn_M, maxloudn_S} (max).  torch.distributed is plumbing here
-(backend "nccl" = RCCL on ROCm for device tensors; "gloo" works on CPU tensors, which is how the
-logic is tested without GPUs).
+and float[4] = {tp_L, tp_R, maxloudn_M, maxloudn_S} (max).
+
+On GPUs that reduction is mtr_engine_reduce(): RCCL INSIDE the C ABI (ncclAllReduce x2 on the engine's
+own communicator, include/mtr_engine.h) — what a C host calls.  torch.distributed is plumbing here: it
+carries the 128-byte RCCL id from rank 0 to the others (make_comm) and provides the barrier of bench.py;
+all_reduce_aggregate() is the same reduction on torch tensors, kept for the CPU tests ("gloo").
 """
 from . import engine as _engine
 
@@ -25,6 +28,15 @@ def all_reduce_aggregate(hist, maxv, group=None):
         dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(maxv, op=dist.ReduceOp.MAX, group=group)
     return hist, maxv
+
+
+def make_comm(rank, world, device=0):
+    """One engine communicator per rank: rank 0 draws the RCCL id, torch.distributed (any backend) ships it."""
+    import torch.distributed as dist
+    uid = [_engine.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    return _engine.Comm(rank, world, uid[0], device)
 
 
 def programme_summary(hist, maxv):

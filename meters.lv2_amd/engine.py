@@ -49,10 +49,10 @@ class StreamResult(C.Structure):
 
 
 def _preload_hip_runtime():
-    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
-    SONAME as /opt/rocm's); if our library pulled in the system copy first and torch then loaded
+    """One HIP runtime and one RCCL per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and librccl.so
+    (same SONAMEs as /opt/rocm's); if our library pulled in the system copies first and torch then loaded
     its own, the second runtime finds no GPU.  When torch is installed (it is only plumbing here:
-    device buffers, torch.distributed) load ITS copy first so both sides share it; without torch
+    device buffers, torch.distributed) load ITS copies first so both sides share them; without torch
     the library's rpath (/opt/rocm/lib) applies."""
     import importlib.util
     try:
@@ -60,9 +60,13 @@ def _preload_hip_runtime():
     except (ImportError, ValueError):
         spec = None
     if spec and spec.submodule_search_locations:
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        for name in ("libamdhip64.so", "librccl.so"):
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+            if os.path.exists(cand):
+                try:
+                    C.CDLL(cand, mode=C.RTLD_GLOBAL if name == "libamdhip64.so" else C.RTLD_LOCAL)
+                except OSError:
+                    pass                      # the system copy (rpath) serves
 
 
 def _load():
@@ -99,6 +103,11 @@ def _load():
     L.mtr_engine_kmeter_reset.argtypes = [vp]
     L.mtr_engine_prune_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_engine_layout.argtypes = [vp]
+    L.mtr_comm_unique_id.argtypes = [vp]
+    L.mtr_comm_init.argtypes = [C.POINTER(vp), i32, i32, vp, i32]
+    L.mtr_comm_destroy.argtypes = [vp]
+    L.mtr_comm_destroy.restype = None
+    L.mtr_engine_reduce.argtypes = [vp, vp, vp, vp, vp]
     L.mtr_hist_loudness.argtypes = [vp, vp] + [C.POINTER(f32)] * 5
     L.mtr_hist_loudness.restype = None
     L.mtr_engine_timing_enable.argtypes = [vp, C.c_int]
@@ -155,6 +164,36 @@ def hist_loudness(hist_M, hist_S):
 def synth_fill_device(ptr, n_streams, n_frames, stride, seed, fs=48000.0, kind=1, stream=0):
     _check(lib.mtr_synth_fill_device(ptr, n_streams, n_frames, stride, seed, fs, kind, stream),
            "mtr_synth_fill_device")
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """Rank 0: the 128-byte RCCL id every rank needs for Comm(...)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib.mtr_comm_unique_id(buf), "comm_unique_id")
+    return bytes(buf.raw)
+
+
+class Comm:
+    """mtr_comm: one RCCL communicator per rank (ncclCommInitRank is collective: every rank constructs its own)."""
+
+    def __init__(self, rank, world, unique_id, device=0):
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _check(lib.mtr_comm_init(C.byref(self._h), rank, world, buf, device), "comm_init")
+
+    def close(self):
+        if self._h:
+            lib.mtr_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class Engine:
@@ -303,6 +342,10 @@ class Engine:
 
     def layout(self):
         return lib.mtr_engine_layout(self._h)
+
+    def reduce(self, comm, hist_ptr, max_ptr, stream=0):
+        """aggregate_device + the RCCL all-reduce across the ranks of `comm` (a Comm), in place, on `stream`."""
+        _check(lib.mtr_engine_reduce(self._h, comm._h, hist_ptr, max_ptr, stream), "reduce")
 
     def prune_stats(self):
         a, b = C.c_uint64(), C.c_uint64()

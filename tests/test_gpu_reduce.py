@@ -1,0 +1,46 @@
+"""mtr_engine_reduce: the job's one collective, RCCL behind the C ABI (include/mtr_engine.h).
+
+  * one rank (any box): a world-of-one communicator — the reduction must be the identity on the aggregate;
+  * two ranks (skipped where the box has one GPU): engine -> aggregate -> ncclAllReduce -> mtr_hist_loudness on
+    two devices against ONE engine over all the streams: identical histograms, peaks and programme record."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_world_of_one_is_the_identity():
+    import torch
+    import meters.lv2_amd as M
+    S, T, fs = 16, 48000 * 3, 48000.0
+    buf = torch.empty((S, T, 2), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    M.synth_fill_device(buf.data_ptr(), S, T, T, 31, fs, 1, st)
+    h0 = torch.zeros(2 * 751, dtype=torch.int32, device="cuda")
+    m0 = torch.zeros(4, dtype=torch.float32, device="cuda")
+    h1, m1 = torch.zeros_like(h0), torch.zeros_like(m0)
+    with M.Comm(0, 1, M.comm_unique_id(), 0) as comm, M.Engine(S, fs, M.METER_EBU | M.METER_TRUEPEAK) as e:
+        e.integr_start()
+        e.process_device(buf.data_ptr(), T, T, st)
+        e.aggregate_device(h0.data_ptr(), m0.data_ptr(), st)
+        e.reduce(comm, h1.data_ptr(), m1.data_ptr(), st)
+        torch.cuda.synchronize()
+    assert int(h0.sum()) > 0 and torch.equal(h0, h1) and torch.equal(m0, m1)
+    with pytest.raises(M.EngineError):
+        M.Comm(2, 2, M.comm_unique_id(), 0)                   # rank outside the world
+
+
+def test_two_ranks_against_one_engine():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (hipGetDeviceCount() < 2 on this box)")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(HERE, "_reduce_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert "REDUCE_OK world=2" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
