@@ -4,31 +4,37 @@
 // bandpass_process / proc_one (src/spectr.c:68-87): mono down-mix, 30 bands x 6 cascaded
 // TDF-II biquads in double, float EMA of v^2 with peak hold.
 //
-// Mapping: one lane per (stream, band) — 32 lanes per stream (30 active), two streams per wave,
-// eight per workgroup.  The 12-state recurrence of a band is serial in time and, with pole
-// radii up to 0.99991, not worth an exact time split (a 12x12 carry matrix per band); with
-// >= 4096 streams there are >= 122k independent lanes, which fills the chip.  The workgroup
-// stages a chunk of frames of its eight streams through LDS with coalesced loads, forming the
-// mono mix (L+R)/2 once per frame instead of once per band; lanes then read the mix as an LDS
-// broadcast.  Coefficients and states live in registers for the whole call.  fp64 VALU bound:
-// ~31 fp64 operations per (frame, band).
+// Mapping: one lane per (stream, band), bands of consecutive streams packed back to back — lane p of the launch is
+// stream p / 30, band p % 30 — so all 64 lanes of every wave work (a layout of 32 lanes per stream idles two in
+// every 32: 6 % of a kernel that issues VALU instructions 100 % of the time).  The 12-state recurrence of a band
+// is serial in time and, with pole radii up to 0.99991, not worth an exact time split (a 12x12 carry matrix per
+// band); with >= 4096 streams there are >= 122k independent lanes, which fills the chip.  A workgroup of 256 lanes
+// covers 8.5 streams: it stages a chunk of frames of the (up to) ten streams it touches through LDS with coalesced
+// loads, forming the mono mix (L+R)/2 and adding the anti-denormal toggle once per frame instead of once per
+// band; lanes then read their stream's row as an LDS broadcast.  Coefficients and states live in registers for the
+// whole call.  fp64 VALU bound: 25 fp64 + 4 fp32 instructions per (frame, band), 4 cycles each, and nothing else in
+// the loop — the kernel runs at that instruction floor (profiles/).
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
 
-#define BANK_SPB   8      /* streams per block */
+#define BANK_ROWS  10     /* streams a block of 256 lanes can touch: ceil (255 / 30) + 1 */
 #define BANK_CHUNK 256    /* frames staged per stream per iteration */
+#define BANK_PITCH (BANK_CHUNK + 2)   /* doubles per row: rows two banks apart, so the <= 4 rows a wave reads never collide */
 
 __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 {
-	__shared__ double mix[BANK_SPB][BANK_CHUNK];   // mono mix + the +-1e-12 anti-denormal toggle, as double
-	__shared__ int    par0[BANK_SPB];
+	__shared__ double mix[BANK_ROWS][BANK_PITCH];  // mono mix + the +-1e-12 anti-denormal toggle, as double
+	__shared__ int    par0[BANK_ROWS];
 
-	const int tid  = threadIdx.x;
-	const int grp  = tid >> 5;                 // stream slot within the block
-	const int band = tid & 31;
-	const uint32_t s = blockIdx.x * BANK_SPB + grp;
-	const bool live = s < a.n_streams && band < MTR_NBANDS;
+	const int tid = threadIdx.x;
+	const uint64_t pair0 = (uint64_t) blockIdx.x * 256;            // first (stream, band) pair of the block
+	const uint64_t pair  = pair0 + tid;
+	const uint32_t s0 = (uint32_t) (pair0 / MTR_NBANDS);           // first stream the block touches
+	const uint32_t s  = (uint32_t) (pair / MTR_NBANDS);
+	const int band = (int) (pair - (uint64_t) s * MTR_NBANDS);
+	const int row  = (int) (s - s0);
+	const bool live = s < a.n_streams;
 
 	double W[6][5];
 	double z[12];
@@ -51,15 +57,17 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 		for (int i = 0; i < 12; ++i) z[i] = 0;
 	}
 	const float omega = a.omega;
-	if (tid < BANK_SPB) { const uint32_t sg = blockIdx.x * BANK_SPB + tid; par0[tid] = sg < a.n_streams ? a.ac[sg] : 0; }
+	if (tid < BANK_ROWS) { const uint32_t sg = s0 + tid; par0[tid] = sg < a.n_streams ? a.ac[sg] : 0; }
 	__syncthreads ();
+	const double* const my = &mix[row][0];
 
 	for (uint64_t base = 0; base < a.n_frames; base += BANK_CHUNK) {
 		const int nf = (int) min ((uint64_t) BANK_CHUNK, a.n_frames - base);
-		// stage: 256 lanes x 8 rows; row g of the block = stream blockIdx*8 + g
+		// stage: 256 lanes x up to 10 rows; row g of the block = stream s0 + g (a stream on a block boundary is
+		// staged by both blocks: 30 bands x 25 fp64 operations stand behind every 8 bytes read)
 #pragma unroll
-		for (int g = 0; g < BANK_SPB; ++g) {
-			const uint32_t sg = blockIdx.x * BANK_SPB + g;
+		for (int g = 0; g < BANK_ROWS; ++g) {
+			const uint32_t sg = s0 + g;
 			float m = 0.f;
 			if (sg < a.n_streams && tid < nf) {
 				if (a.n_channels == 2) {
@@ -78,8 +86,8 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 		for (int n = 0; n < nf; ++n) {
 			// six TDF-II sections (spectr.c:68-76).  Section 0 carries the normalisation g: numerator
 			// g (1, 2, 1); sections 1-5 have (1, +-2, 1): b0 in = b2 in = in and b1 in = +-2 in are exact, so
-			// sharing the product changes nothing but the operation count (26 instead of 31 fp64 ops).
-			double out = mix[grp][n];
+			// sharing the product changes nothing but the operation count (25 instead of 31 fp64 ops).
+			double out = my[n];
 			{
 				const double gi = W[0][0] * out;
 				const double y = gi + z[0];
@@ -97,7 +105,8 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 			const float v = (float) out;
 			const float q = v * v;
 			val += omega * (q - val);
-			mx = val > mx ? val : mx;
+			// `val > mx ? val : mx` (spectrumlv2.c:222) as one v_max_f32: a NaN val loses either way, mx is never NaN
+			mx = __builtin_fmaxf (mx, val);
 		}
 		__syncthreads ();
 	}
@@ -113,13 +122,14 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 		}
 		a.val[(size_t) s * MTR_NBANDS + band] = val + 1e-20f;
 		a.mx[(size_t) s * MTR_NBANDS + band]  = mx;
-		if (band == 0) a.ac[s] = par0[grp] ^ (int) (a.n_frames & 1);
+		if (band == 0) a.ac[s] = par0[row] ^ (int) (a.n_frames & 1);
 	}
 }
 
 int mtr_launch_bank (const mtr_bank_args& a, void* stream)
 {
-	const uint32_t nb = (a.n_streams + BANK_SPB - 1) / BANK_SPB;
+	const uint64_t pairs = (uint64_t) a.n_streams * MTR_NBANDS;
+	const uint32_t nb = (uint32_t) ((pairs + 255) / 256);
 	hipLaunchKernelGGL (k_bank, dim3 (nb), dim3 (256), 0, (hipStream_t) stream, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
