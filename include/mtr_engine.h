@@ -155,7 +155,10 @@ int  mtr_engine_spectrum (mtr_engine* e, uint32_t first, uint32_t count,
 int  mtr_engine_bitstats (mtr_engine* e, uint32_t first, uint32_t count,
                           int32_t* hist, int32_t* counters, float* minmax);
 /* replaces: the state sdh_run's loop maintains (src/sigdistlv2.c:296-327): bins [count][361],
- *   peak [count][2] = {count, bin}, moments [count][3] = {sum, mean, M2} (double), n [count] */
+ *   peak [count][2] = {count, bin}, moments [count][3] = {sum, mean, M2} (double), n [count].
+ *   mean / M2 are the Welford moments of the BINNED samples: the reference's once a sample fell outside the 361
+ *   bins divides by the index among all samples (:312-315) and stops being a mean — that quirk is not mirrored;
+ *   bins, peak, n and sum are bit-identical in every case. */
 int  mtr_engine_sigdist (mtr_engine* e, uint32_t first, uint32_t count,
                          int32_t* bins, int32_t* peak, double* moments, int64_t* n);
 /* replaces: bim_reset (src/bitmeter.c:47-60) and the SDH reset */

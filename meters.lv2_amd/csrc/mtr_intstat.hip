@@ -7,7 +7,15 @@
 // 361 bins (this TU is built with -ffp-contract=off: the bin decision must not see an FMA),
 // peak bin (ties: the bin that reached the final maximum first, as the sequential `>` test gives),
 // sum and Welford mean / M2 in double (combined across lanes with Chan's formula: equal to the
-// sequential recurrence up to double rounding).
+// sequential recurrence up to double rounding) — OVER THE BINNED SAMPLES.
+//
+// Stated deviation: the reference's running mean divides by `integration_time + s + 1` (:312-315), the index of
+// the sample among ALL samples, also those it skipped as out of range (|x| > 1.2, NaN).  While every sample is
+// binned — normalised audio — that is exactly Welford's recurrence and the two agree to double rounding.  Once
+// a sample has been skipped, the reference's var_m / var_s are no longer the mean and M2 of anything (later
+// samples weigh 1 / index instead of 1 / count); this kernel keeps the true moments of the binned samples
+// instead of mirroring that.  Bins, peak bin, sample count and the plain sum `avg` are not affected: they are
+// the reference's bit for bit with or without skipped samples (tests/test_gpu_intstat.py checks both regimes).
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"

@@ -8,7 +8,8 @@ import struct
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PLUGIN_SO = os.path.join(ROOT, "meters.lv2_amd", "lib", "meters_amd.so")
+# MTR_PLUGIN_SO: an instrumented build of the same plugin (make check-asan)
+PLUGIN_SO = os.environ.get("MTR_PLUGIN_SO") or os.path.join(ROOT, "meters.lv2_amd", "lib", "meters_amd.so")
 MTR_URI = "http://gareus.org/oss/lv2/meters#"
 ATOM = "http://lv2plug.in/ns/ext/atom#"
 

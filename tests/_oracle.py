@@ -27,7 +27,10 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 
 def build_oracle():
-    """(Re)build the oracle .so with gcc if missing or stale. Cheap (≈1 s)."""
+    """(Re)build the oracle .so with gcc if missing or stale. Cheap (≈1 s).  MTR_ORACLE_SO: an instrumented build
+    of the same sources (make check-asan)."""
+    if os.environ.get("MTR_ORACLE_SO"):
+        return os.environ["MTR_ORACLE_SO"]
     src = [os.path.join(ORACLE_DIR, f) for f in ("mtr_oracle.c", "mtr_oracle.h")]
     if (not os.path.exists(ORACLE_SO)
             or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(s) for s in src)):
