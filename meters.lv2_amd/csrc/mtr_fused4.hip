@@ -165,12 +165,17 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		const int nslot = len + off;
 		const bool tail_odd = (t0 + len == (int64_t) a.n_frames) && (a.n_frames & 1);
 		if (src_even && !tail_odd) {
-			const v2f* const p = src + (t0 - off) + 2 * lane;
-			for (int i = 0; i < nslot; i += 128) {
-				if (i + 2 * lane < nslot)
-				__builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void*) (p + i),
-				                                  (__attribute__ ((address_space (3))) void*) (buf + HALO + i), 16, 0, 0);
-			}
+			// whole 1 KiB pieces first (128 slots each, every lane takes part), four per address update, then the
+			// tile's last, partial piece under a lane mask
+			const v2f* p = src + (t0 - off) + 2 * lane;
+			v2f* d = buf + HALO;
+#define MTR_DMA(k) __builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void*) (p + 128 * (k)), \
+                                                     (__attribute__ ((address_space (3))) void*) (d + 128 * (k)), 16, 0, 0)
+			int i = 0;
+			for (; i + 512 <= nslot; i += 512, p += 512, d += 512) { MTR_DMA (0); MTR_DMA (1); MTR_DMA (2); MTR_DMA (3); }
+			for (; i + 128 <= nslot; i += 128, p += 128, d += 128) MTR_DMA (0);
+			if (i + 2 * lane < nslot) MTR_DMA (0);
+#undef MTR_DMA
 		} else {
 			for (int i = lane; i < nslot; i += 64) buf[HALO + i] = src[t0 - off + i];
 		}
@@ -375,9 +380,13 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 			m16::f4 yl[3], yr[3];
 #pragma unroll
 			for (int p = 0; p < 3; ++p) yr[p] = m16::f4{0.f, 0.f, 0.f, 0.f};
-			m16::fetch_b (bl, HL, LL, min (col8, 8 * CMAX) + kg4);
-			for (int b = 0; b < nfull; ++b) {
-				m16::fetch_b (br, HR, LR, min (128 * b + col8, 8 * CMAX) + kg4);
+			// word index of this lane's window in block b: 128 b + col8 + kg4.  Full blocks lie inside the arrays; only the
+			// partial block's trailing columns can start past the last whole window and are clamped (their outputs are masked).
+			int w = col8 + kg4;
+			const int wlast = min (128 * nfull + col8, 8 * CMAX) + kg4;
+			m16::fetch_b (bl, HL, LL, nfull ? w : wlast);
+			for (int b = 0; b < nfull; ++b, w += 128) {
+				m16::fetch_b (br, HR, LR, w);
 				__builtin_amdgcn_sched_barrier (0);
 				m16::block (A, bl, yl);
 #pragma unroll
@@ -385,7 +394,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 #pragma unroll
 				for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier (0x8, 3, 0); __builtin_amdgcn_sched_group_barrier (0x2, 1, 0); }
 				__builtin_amdgcn_sched_barrier (0);
-				m16::fetch_b (bl, HL, LL, min (128 * (b + 1) + col8, 8 * CMAX) + kg4);   // past the last block: a harmless clamped read
+				m16::fetch_b (bl, HL, LL, b + 1 < nfull ? w + 128 : wlast);   // past the last block: a harmless clamped read
 				__builtin_amdgcn_sched_barrier (0);
 				m16::block (A, br, yr);
 #pragma unroll
@@ -398,7 +407,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 			for (int p = 0; p < 3; ++p) { pr = max3abs (pr, yr[p][0], yr[p][1]); pr = max3abs (pr, yr[p][2], yr[p][3]); }
 			if (len & 255) {
 				// the tile's last block: frames past its end belong to the next tile (or do not exist yet)
-				m16::fetch_b (br, HR, LR, min (128 * nfull + col8, 8 * CMAX) + kg4);
+				m16::fetch_b (br, HR, LR, wlast);
 				m16::block (A, bl, yl);
 				m16::block (A, br, yr);
 				const int lim = len - 256 * nfull - fo;                      // registers r < lim are outputs of this tile
