@@ -47,10 +47,14 @@ def atom_port(idx, sym, name, direction, extra=""):
 
 
 def plugin(uri, name, comment, ports, extra=""):
+    """The reference's plugins all carry lv2:hardRTCapable (lv2ttl/meters.lv2.ttl.in:609).  Here only the ones whose run()
+    stays on the host CPU do: a run() that copies to the GPU, launches kernels and waits for them takes driver locks,
+    however short it is (26 - 132 us per 1024-frame block)."""
     body = " ] , [\n".join(ports)
+    rt = "" if "GPU" in comment else "\tlv2:optionalFeature lv2:hardRTCapable ;\n"
     return ("mtr:%s\n\ta lv2:Plugin , lv2:AnalyserPlugin , doap:Project ;\n\tdoap:license <http://usefulinc.com/doap/licenses/gpl> ;\n"
-            "\tdoap:name \"%s\" ;\n\tlv2:project <http://gareus.org/oss/lv2/meters> ;\n\tlv2:optionalFeature lv2:hardRTCapable ;\n%s"
-            "\tlv2:port [\n%s\t] ;\n\trdfs:comment \"%s\"\n\t.\n\n" % (uri, name, extra, body, comment))
+            "\tdoap:name \"%s\" ;\n\tlv2:project <http://gareus.org/oss/lv2/meters> ;\n%s%s"
+            "\tlv2:port [\n%s\t] ;\n\trdfs:comment \"%s\"\n\t.\n\n" % (uri, name, rt, extra, body, comment))
 
 
 def spectr(stereo):
@@ -155,7 +159,7 @@ def dr14s():
             ports.append(ctl(18, "dr_total", "DR", "Output", 1.0, 21.0))
         label = ("DR-14 Crest-Factor Meter" if n.startswith("dr14") else "True-Peak and RMS Meter") + \
             (" (Stereo, MI355X build)" if stereo else " (Mono, MI355X build)")
-        t += plugin(n, label, "True-peak ballistics on the GPU; RMS and 3 s window statistics on the host.", ports,
+        t += plugin(n, label, "True-peak ballistics, K-meter detector and the 3 s window statistics on the GPU.", ports,
                     extra="\tlv2:requiredFeature urid:map ;\n")
     return t
 
