@@ -120,7 +120,7 @@ __device__ __forceinline__ void pow2_scale (uint32_t e_, float& scale, float& un
 	unscale = __uint_as_float ((uint32_t) (239 - se) << 23);      // 2^-(se - 127) * 2^-15
 }
 
-template <int K, bool EBU>
+template <int K, bool EBU, bool REGPF>
 __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 {
 	static_assert ((K & 1) == 0, "even runs: sample pairs never straddle two lanes");
@@ -183,6 +183,35 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		for (int i = HALO + ((nslot + 1) & ~1) + lane; i < HALO + off + LT; i += 64) buf[i] = v2f{0.f, 0.f};
 	};
 
+	// REGPF: the next tile goes straight into the run registers — which are dead during the products — with per-lane
+	// global loads issued BEFORE the MFMA phase: lane l reads its own 304 contiguous bytes (19 x 16 bytes; the 64 lanes
+	// of one instruction touch 64 cache lines, each of which the following seven instructions hit again in the L1),
+	// lanes 0..23 the two halo frames in front of the tile.  No f32 image in LDS, no DMA issue behind the products, no
+	// transposing read: the stream arrives under the matrix work.  Frames past the tile in the last lanes' runs are the
+	// next tile's (real, finite or not): every use below masks them (K-filter: lane masks; products: outputs past the
+	// tile are masked and no valid output's window reaches them; scale: lanes past the tile are left out).
+	const v2f* const hst = reinterpret_cast<const v2f*> (a.hist) + (size_t) s * MTR_FIR_HALO;
+	auto frame_at = [&] (int64_t f) -> v2f {                             // call-relative frame, history in front of frame 0
+		if (f >= 0) return src[f];
+		if (f >= -MTR_FIR_HALO && q == 0) return hst[f + MTR_FIR_HALO];
+		return v2f{0.f, 0.f};
+	};
+	auto fetch = [&] (int jj, v2f (&xn)[K], v2f& g0, v2f& g1) {
+		int64_t t0; int len;
+		tile_of (jj, t0, len);
+		const int64_t base = t0 + (int64_t) K * lane;
+		if (src_even && !(t0 & 1) && t0 + (int64_t) LT <= (int64_t) a.n_frames) {
+			const float4* const p4 = reinterpret_cast<const float4*> (src + base);
+#pragma unroll
+			for (int i = 0; i < K / 2; ++i) { const float4 v = p4[i]; xn[2 * i] = v2f{v.x, v.y}; xn[2 * i + 1] = v2f{v.z, v.w}; }
+		} else {
+#pragma unroll
+			for (int n = 0; n < K; ++n) xn[n] = base + n < (int64_t) a.n_frames ? src[base + n] : v2f{0.f, 0.f};
+		}
+		g0 = v2f{0.f, 0.f}; g1 = v2f{0.f, 0.f};
+		if (lane < HALO / 2) { g0 = frame_at (t0 - HALO + 2 * lane); g1 = frame_at (t0 - HALO + 2 * lane + 1); }
+	};
+
 	v2f k1 = 0, k2 = 0, k3 = 0, k4 = 0;            // carried K-filter state, wave-uniform
 	if (EBU && q == 0) {
 		k1 = v2f{st->kz[0], st->kz[1]}; k2 = v2f{st->kz[2], st->kz[3]};
@@ -201,18 +230,20 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 	// halo of the first tile: the 47 frames before the call behind one zero (segment 0); later segments start with
 	// warm-up tiles, whose own halo is never multiplied.  Lane i < 24 holds positions 2 i and 2 i + 1.
 	v2f h0 = v2f{0.f, 0.f}, h1 = v2f{0.f, 0.f};
-	if (q == 0 && lane < HALO / 2) {
-		const v2f* const h = reinterpret_cast<const v2f*> (a.hist) + (size_t) s * MTR_FIR_HALO;
-		if (lane > 0) h0 = h[2 * lane - 1];
-		h1 = h[2 * lane];
-	}
-	{
+	v2f x[K];
+	if (REGPF) {
+		fetch (-nwarm, x, h0, h1);
+	} else {
+		if (q == 0 && lane < HALO / 2) {
+			if (lane > 0) h0 = hst[2 * lane - 1];
+			h1 = hst[2 * lane];
+		}
 		int64_t t0; int len;
 		tile_of (-nwarm, t0, len);
 		const int off = (int) (t0 & 1);
 		if (lane < HALO / 2) { buf[off + 2 * lane] = h0; buf[off + 2 * lane + 1] = h1; }
+		stage (-nwarm);
 	}
-	stage (-nwarm);
 	const int wrun = HALO / 2 + (K / 2) * lane;                        // first word of this lane's run in each array
 	const int col8 = 8 * (lane & 15), kg4 = 4 * (lane >> 4);
 
@@ -225,29 +256,31 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		const int off = (int) (t0 & 1);
 
 		PROF_NOW (c0_);
-		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed (in LDS, or in the run registers)
 		PROF_NOW (c1_); PROF_ADD (0, c1_ - c0_);
-		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
-		if (((len + off) & 1) && lane == 0) buf[HALO + off + len] = v2f{0.f, 0.f};
 		// the per-lane matrices of the scan's row-broadcast steps: 24 registers, fetched per tile (L1 / L2 hits that
 		// land under the split) rather than held across the products
 		mtrw::RowMats rm;
 		if (EBU) rm.load (a.scan_m + 96 + 4 * K + 4, lane);
 
-		v2f x[K];
-		if (off == 0) {
-			const float4* const p4 = reinterpret_cast<const float4*> (buf + HALO + K * lane);
-#pragma unroll
-			for (int i = 0; i < K / 2; ++i) { const float4 v = p4[i]; x[2 * i] = v2f{v.x, v.y}; x[2 * i + 1] = v2f{v.z, v.w}; }
-		} else {
-			const v2f* const xr = buf + HALO + 1 + K * lane;
-#pragma unroll
-			for (int n = 0; n < K; ++n) x[n] = xr[n];
-		}
-		// this tile's halo (positions 0..47) is in h0 / h1; the next one's = the last 48 positions of halo ++ tile
+		// this tile's halo (positions 0..47) is in h0 / h1
 		const v2f ph0 = h0, ph1 = h1;
-		if (lane < HALO / 2) { h0 = buf[off + len + 2 * lane]; h1 = buf[off + len + 2 * lane + 1]; }
-		asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");    // every read has returned: the f32 image is dead
+		if (!REGPF) {
+			__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+			if (((len + off) & 1) && lane == 0) buf[HALO + off + len] = v2f{0.f, 0.f};
+			if (off == 0) {
+				const float4* const p4 = reinterpret_cast<const float4*> (buf + HALO + K * lane);
+#pragma unroll
+				for (int i = 0; i < K / 2; ++i) { const float4 v = p4[i]; x[2 * i] = v2f{v.x, v.y}; x[2 * i + 1] = v2f{v.z, v.w}; }
+			} else {
+				const v2f* const xr = buf + HALO + 1 + K * lane;
+#pragma unroll
+				for (int n = 0; n < K; ++n) x[n] = xr[n];
+			}
+			// the next tile's halo = the last 48 positions of halo ++ tile
+			if (lane < HALO / 2) { h0 = buf[off + len + 2 * lane]; h1 = buf[off + len + 2 * lane + 1]; }
+			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");    // every read has returned: the f32 image is dead
+		}
 		PROF_NOW (c2_); PROF_ADD (1, c2_ - c1_);
 
 		// per-lane max |x| per channel
@@ -258,7 +291,8 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		if (lane < HALO / 2) { hl = fmaxf (fabsf (ph0.x), fabsf (ph1.x)); hr = fmaxf (fabsf (ph0.y), fabsf (ph1.y)); }
 		// The scales need only the exponents of the two window maxima: both ride through ONE wave reduction as a pair
 		// of 16-bit fields (v_pk_max_u16); NaNs have lost every fmaxf above, an Inf gives exponent 255.
-		const uint32_t epair = (__float_as_uint (fmaxf (ml, hl)) >> 23) | ((__float_as_uint (fmaxf (mr, hr)) >> 23) << 16);
+		const bool inside = !REGPF || K * lane < len;                 // REGPF: lanes past the tile hold the next tile's frames
+		const uint32_t epair = (__float_as_uint (fmaxf (inside ? ml : 0.f, hl)) >> 23) | ((__float_as_uint (fmaxf (inside ? mr : 0.f, hr)) >> 23) << 16);
 		const uint32_t emax = mtrw::max63_u16x2 (epair);
 
 		// Phase 0 (|x[n - 24]|) of this call covers frames [-24, n_frames - 24): every frame of the tile unless the call
@@ -266,7 +300,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		// kept per lane and reduced once, at the end of the segment.
 		if (jj >= 0) {
 			float il = ml, ir = mr;
-			if (t0 + len > id_end) {
+			if (t0 + (REGPF ? LT : len) > id_end) {
 				il = 0.f; ir = 0.f;
 				const int64_t lim = id_end - t0 - (int64_t) K * lane;          // frames of this lane's run inside the range
 #pragma unroll
@@ -287,7 +321,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		// Only this option needs the maxima and the peaks so far wave-wide, per tile.
 		bool need_l = jj >= 0, need_r = jj >= 0;
 		if (a.prune && jj >= 0) {
-			const float tml = mtrw::max63 (fmaxf (ml, hl)), tmr = mtrw::max63 (fmaxf (mr, hr));
+			const float tml = mtrw::max63 (fmaxf (inside ? ml : 0.f, hl)), tmr = mtrw::max63 (fmaxf (inside ? mr : 0.f, hr));
 			const float run_l = mtrw::max63 (pk_l), run_r = mtrw::max63 (pk_r);
 			need_l = 2.5684f * 1.002f * tml > run_l;
 			need_r = 2.5684f * 1.002f * tmr > run_r;
@@ -366,6 +400,9 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		}
 
 		PROF_NOW (c5_); PROF_ADD (4, c5_ - c4_);
+		// REGPF: the run registers are dead from here on: the next tile's loads go out now and land under the products
+		v2f xn[K], g0 = v2f{0.f, 0.f}, g1 = v2f{0.f, 0.f};
+		if (REGPF && jj + 1 < ntile) fetch (jj + 1, xn, g0, g1);
 		// The interpolator: 256 output frames x 3 phases per block and channel.  Operands ping-pong between the channels:
 		// the right channel's fragments land under the left channel's 18 products and the next block's left fragments
 		// under the right channel's; each channel's |max| rides between the other channel's MFMAs (two VALU
@@ -435,8 +472,13 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		}
 		PROF_NOW (c6_); PROF_ADD (5, c6_ - c5_);
 
-		// the next tile: halo as f32 in front of it, DMA over the spent words
-		if (jj + 1 < ntile) {
+		if (REGPF) {
+#pragma unroll
+			for (int n = 0; n < K; ++n) x[n] = xn[n];
+			h0 = g0; h1 = g1;
+		}
+		// (LDS-staged form) the next tile: halo as f32 in front of it, DMA over the spent words
+		if (!REGPF && jj + 1 < ntile) {
 			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
 			int64_t t1; int len1;
 			tile_of (jj + 1, t1, len1);
@@ -471,8 +513,14 @@ int launch_kwtp16 (bool ebu, const mtr_fused_args& a, uint32_t n_units, hipStrea
 	const size_t words = (size_t) 4 * ((HALO + 64 * K) / 2) * sizeof (uint32_t);
 	const size_t tile = (size_t) (HALO + 1 + 64 * K) * sizeof (v2f);
 	const size_t lds = ((words > tile ? words : tile) + 15) & ~(size_t) 15;
-	if (ebu) hipLaunchKernelGGL ((k_kwtp16<K, true>), dim3 (n_units), dim3 (64), lds, st, a);
-	else     hipLaunchKernelGGL ((k_kwtp16<K, false>), dim3 (n_units), dim3 (64), lds, st, a);
+	// tune_fir = 3: the LDS-staged form (LDS-DMA of the f32 tile, transposing read), kept for comparison
+	if (a.fir_form == 3) {
+		if (ebu) hipLaunchKernelGGL ((k_kwtp16<K, true, false>), dim3 (n_units), dim3 (64), lds, st, a);
+		else     hipLaunchKernelGGL ((k_kwtp16<K, false, false>), dim3 (n_units), dim3 (64), lds, st, a);
+	} else {
+		if (ebu) hipLaunchKernelGGL ((k_kwtp16<K, true, true>), dim3 (n_units), dim3 (64), lds, st, a);
+		else     hipLaunchKernelGGL ((k_kwtp16<K, false, true>), dim3 (n_units), dim3 (64), lds, st, a);
+	}
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
