@@ -52,6 +52,7 @@ typedef struct {
 	int ui_active, send_state_to_ui;
 	int transport_mode, rolling;             /* (sic) the reference's spelling */
 	int integrating, dbtp_enable;
+	int failing;               /* an engine call failed in the last run (): lv2_engine_ok */
 	uint32_t ui_flags;
 
 	float *ring_s, *ring_m;
@@ -262,10 +263,16 @@ void ebur128_run (LV2_Handle h, uint32_t n_samples)
 
 	/* audio, :340-347: one batch-of-one launch; results come back in one record */
 	const float* in[2] = { p->input[0], p->input[1] };
-	if (n_samples > 0) mtr_engine_process_planar_host (p->amd, in, n_samples);
+	int rc = MTR_OK;
+	if (n_samples > 0) rc = mtr_engine_process_planar_host (p->amd, in, n_samples);
 	mtr_stream_result r;
 	memset (&r, 0, sizeof (r));
-	mtr_engine_results (p->amd, 0, 1, &r);
+	if (rc == MTR_OK) rc = mtr_engine_results (p->amd, 0, 1, &r);
+	if (!lv2_engine_ok (rc, &p->failing, "EBUr128")) {
+		/* no measurement this cycle: every level of the record is NaN (lv2_plugins.h), nothing is accumulated */
+		r.loudness_M = r.maxloudn_M = r.loudness_S = r.maxloudn_S = r.integrated = MTR_LV2_NO_DATA;
+		r.range_min = r.range_max = r.integ_thr = r.range_thr = MTR_LV2_NO_DATA;
+	}
 	const float lm = r.loudness_M, ls = r.loudness_S;
 
 	if (p->dbtp_enable) {                                  /* :360-367 */

@@ -43,6 +43,7 @@ typedef struct {
 	Forge fg;
 	double rate;
 	mtr_engine* amd;
+	int failing;               /* an engine call failed in the last run (): lv2_engine_ok */
 
 	int ui_active, send_state_to_ui, integrating;
 	int64_t integ_frames;
@@ -125,7 +126,9 @@ static void acquire (IntStat* p, uint32_t n_samples)
 		return;
 	}
 	const float* in[1] = { p->input[0] };
-	if (n_samples > 0) mtr_engine_process_planar_host (p->amd, in, n_samples);
+	/* a block the engine could not take is not counted: the tables (integer counts, sent to the UI as such) stay what
+	 * they were and integration time does not advance — reported once per failure streak (lv2_plugins.h) */
+	if (n_samples > 0 && !lv2_engine_ok (mtr_engine_process_planar_host (p->amd, in, n_samples), &p->failing, "bitmeter / SigDistHist")) return;
 	p->integ_frames += n_samples;
 }
 

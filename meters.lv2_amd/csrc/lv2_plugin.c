@@ -79,6 +79,7 @@ typedef struct {
 	float    unread_m[2], unread_p[2];
 	VuDsp    vu[2];
 	mtr_engine* amd;
+	int failing;               /* an engine call failed in the last run (): lv2_engine_ok */
 } Meter;
 
 static LV2_Handle meter_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* f)
@@ -143,7 +144,7 @@ static void vu_run (LV2_Handle h, uint32_t n_samples)
 	for (uint32_t c = 0; c < self->chn; ++c) {
 		vu_process (&self->vu[c], self->input[c], (int) n_samples);
 		*self->level[c] = self->rlgain * vu_read (&self->vu[c]);
-		if (self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
+		if (self->input[c] && self->output[c] && self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
 	}
 }
 
@@ -164,13 +165,20 @@ static void dbtp_run (LV2_Handle h, uint32_t n_samples)
 	if (fabsf (*self->reflvl) == 3) reinit_gui = 1;
 
 	const float* in[2] = { self->input[0], self->input[1] };
-	if (n_samples > 0) mtr_engine_process_planar_host (self->amd, in, n_samples);
+	int rc = MTR_OK;
+	if (n_samples > 0) rc = mtr_engine_process_planar_host (self->amd, in, n_samples);
 	for (uint32_t c = 0; c < self->chn; ++c)
-		if (self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
+		if (self->input[c] && self->output[c] && self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
 
 	mtr_stream_result r;
 	memset (&r, 0, sizeof (r));
-	if (n_samples > 0 && mtr_engine_results (self->amd, 0, 1, &r) != MTR_OK) return;
+	if (n_samples > 0 && rc == MTR_OK) rc = mtr_engine_results (self->amd, 0, 1, &r);
+	if (!lv2_engine_ok (rc, &self->failing, "dBTP")) {
+		for (uint32_t c = 0; c < self->chn; ++c) *self->level[c] = MTR_LV2_NO_DATA;
+		if (self->chn == 1) *self->input[1] = MTR_LV2_NO_DATA;      /* port index 4: the mono peak output */
+		else { *self->peak[0] = MTR_LV2_NO_DATA; *self->peak[1] = MTR_LV2_NO_DATA; }
+		return;
+	}
 	/* TruePeakdsp keeps max-accumulating until read (m, p) is called (truepeakdsp.cc:91-98): a block
 	 * whose run() returned early below is folded into the next read. */
 	float m[2], p[2];
@@ -225,6 +233,7 @@ typedef struct {
 	float  rst_h, spd_h;
 	uint32_t nchannels;
 	mtr_engine* amd;
+	int failing;               /* an engine call failed in the last run (): lv2_engine_ok */
 } Spec;
 
 static LV2_Handle spectrum_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* f)
@@ -292,17 +301,21 @@ static void spectrum_run (LV2_Handle h, uint32_t n_samples)
 	if (fabsf (*self->rst_p) == 3) reinit_gui = 1;
 
 	const float* in[2] = { self->input[0], self->input[1] };
-	if (n_samples > 0) mtr_engine_process_planar_host (self->amd, in, n_samples);
+	int rc = MTR_OK;
+	if (n_samples > 0) rc = mtr_engine_process_planar_host (self->amd, in, n_samples);
 
 	float val_db[MTR_NBANDS], max_db[MTR_NBANDS];
-	if (mtr_engine_spectrum (self->amd, 0, 1, NULL, NULL, val_db, max_db) == MTR_OK) {
+	if (rc == MTR_OK) rc = mtr_engine_spectrum (self->amd, 0, 1, NULL, NULL, val_db, max_db);
+	if (lv2_engine_ok (rc, &self->failing, "spectr30")) {
 		for (int i = 0; i < MTR_NBANDS; ++i) {
 			*self->spec[i] = val_db[i];
 			*self->maxf[i] = reinit_gui ? (float) (-500 - (rand () & 0xffff)) : max_db[i];
 		}
+	} else {
+		for (int i = 0; i < MTR_NBANDS; ++i) { *self->spec[i] = MTR_LV2_NO_DATA; *self->maxf[i] = MTR_LV2_NO_DATA; }
 	}
 	for (uint32_t c = 0; c < self->nchannels; ++c)
-		if (self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
+		if (self->input[c] && self->output[c] && self->input[c] != self->output[c]) memcpy (self->output[c], self->input[c], sizeof (float) * n_samples);
 }
 
 static void spectrum_cleanup (LV2_Handle h)

@@ -3,7 +3,25 @@
 #ifndef MTR_LV2_PLUGINS_H
 #define MTR_LV2_PLUGINS_H
 
+#include <math.h>
+#include <stdio.h>
+
 #include "lv2_min.h"
+#include "mtr_engine.h"
+
+/* An LV2 run() has no error channel, and the reference never fails inside one.  The GPU plugins can (a device that
+ * went away mid-session): a failing engine call is reported ONCE per failure streak on stderr, and the plugin then
+ * writes MTR_LV2_NO_DATA — a quiet NaN, which no meter of the bundle ever produces — to its meter outputs instead of
+ * leaving the last good values there, so a host or GUI can tell "no measurement" from "unchanged level".  Audio is
+ * still passed through. */
+#define MTR_LV2_NO_DATA ((float) NAN)
+static inline int lv2_engine_ok (int rc, int* failing, const char* who)
+{
+	if (rc == MTR_OK) { *failing = 0; return 1; }
+	if (!*failing) fprintf (stderr, "meters_amd: %s: %s — meter outputs carry NaN until the engine answers again\n", who, mtr_last_error ());
+	*failing = 1;
+	return 0;
+}
 
 /* lv2_ebur128.c — src/ebulv2.cc */
 LV2_Handle  ebur128_instantiate (const LV2_Descriptor* d, double rate, const char* path, const LV2_Feature* const* features);

@@ -86,8 +86,9 @@ class Instance:
         return bool(self.handle)
 
     def connect(self, port, array):
+        """array = None disconnects the port (LV2 allows connect_port (instance, port, NULL))."""
         self.ports[port] = array
-        self.desc.connect_port(self.handle, port, array.ctypes.data_as(C.c_void_p))
+        self.desc.connect_port(self.handle, port, array.ctypes.data_as(C.c_void_p) if array is not None else None)
 
     def run(self, n):
         self.desc.run(self.handle, n)

@@ -186,3 +186,34 @@ def test_spectr30_stereo(host, oracle):
 
 
 # The EBUr128 plugin has its own file: tests/test_lv2_ebur128.py (the whole UI protocol, message by message).
+
+
+@pytest.mark.gpu
+def test_engine_failure_is_signalled_not_hidden(host, capfd):
+    """an engine call that fails inside run() (here: an audio input port left unconnected, which
+    the engine refuses) must not leave the last good values on the meter ports: they carry NaN until the engine
+    answers again, and the error is reported once per failure streak."""
+    inst = Instance(host, "spectr30stereo")
+    assert inst.ok()
+    spec = [_f() for _ in range(30)]
+    mx = [_f() for _ in range(30)]
+    spd, rst, amp, st = _f(1.0), _f(-4.0), _f(0.0), _f(0.0)
+    for i in range(30):
+        inst.connect(i, spec[i]); inst.connect(30 + i, mx[i])
+    for port, arr in ((60, spd), (61, rst), (62, amp), (63, st)):
+        inst.connect(port, arr)
+    x = sig.sine(4096, 1000.0, 0.5)
+    bl, br = x[:1024, 0].copy(), x[:1024, 1].copy()
+    for port, arr in ((64, bl), (65, bl), (66, br), (67, br)):
+        inst.connect(port, arr)
+    inst.run(1024)
+    assert all(np.isfinite(s[0]) for s in spec)
+    inst.connect(64, None); inst.connect(66, None)            # the inputs go away
+    inst.run(1024); inst.run(1024)
+    assert all(np.isnan(s[0]) for s in spec) and all(np.isnan(m[0]) for m in mx)
+    err = capfd.readouterr().err
+    assert err.count("meters_amd: spectr30") == 1              # once per streak, not once per block
+    inst.connect(64, bl); inst.connect(66, br)
+    inst.run(1024)
+    assert all(np.isfinite(s[0]) for s in spec)
+    inst.cleanup()
