@@ -216,6 +216,58 @@ static void run_mix (const char* name, int wg_per_cu, float* d_out, unsigned lon
 	fflush (stdout);
 }
 
+// ---- the exact alternative: the interpolator on v_mfma_f32_32x32x2_f32 (f32 in, bit-for-bit an fmaf
+// chain) beside a wave of packed-f32 K-filter work on the same SIMD.  One 32x32x2 MFMA = 2048 MACs in 64 cycles.
+template <int ROLE>      // 1 = MFMA only, 2 = VALU only, 3 = waves 0-3 MFMA, waves 4-7 VALU
+__global__ void k_f32mfma (float* out, unsigned long long* cyc, int iters, float seed)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	f16v c[4];
+	for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) c[i][j] = 0;
+	float a = 0.001f * lane + seed, b = 0.002f * lane - seed;
+	v2f p[8];
+	for (int i = 0; i < 8; ++i) p[i] = v2f{seed + i, seed - lane};
+	const v2f mp = v2f{0.999f + seed, 0.999f + seed};
+	const bool do_m = ROLE == 1 || (ROLE == 3 && wave < 4), do_v = ROLE == 2 || (ROLE == 3 && wave >= 4);
+	unsigned long long t0 = __builtin_readcyclecounter ();
+	for (int it = 0; it < iters; ++it) {
+		if (do_m) {
+#pragma unroll
+			for (int k = 0; k < 16; ++k) c[k & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32 (a, b, c[k & 3], 0, 0, 0);
+		}
+		if (do_v) {
+#pragma unroll
+			for (int k = 0; k < 128; ++k) p[k & 7] = p[k & 7] * mp + mp;
+		}
+	}
+	unsigned long long t1 = __builtin_readcyclecounter ();
+	float r = 0;
+	for (int i = 0; i < 8; ++i) r += p[i].x + p[i].y;
+	for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) r += c[i][j];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+	if (blockIdx.x == 0 && lane == 0) cyc[wave] = t1 - t0;
+}
+
+template <int ROLE>
+static void run_f32 (const char* name, int threads, float* d_out, unsigned long long* d_cyc)
+{
+	const int iters = 400, grid = 256;
+	hipEvent_t e0, e1;
+	hipEventCreate (&e0); hipEventCreate (&e1);
+	hipLaunchKernelGGL (k_f32mfma<ROLE>, dim3 (grid), dim3 (threads), 0, 0, d_out, d_cyc, 4, 0.f);
+	hipDeviceSynchronize ();
+	hipEventRecord (e0);
+	hipLaunchKernelGGL (k_f32mfma<ROLE>, dim3 (grid), dim3 (threads), 0, 0, d_out, d_cyc, iters, 0.f);
+	hipEventRecord (e1);
+	hipEventSynchronize (e1);
+	float ms;
+	hipEventElapsedTime (&ms, e0, e1);
+	unsigned long long c[8] = {0};
+	hipMemcpy (c, d_cyc, sizeof (c), hipMemcpyDeviceToHost);
+	printf ("%-72s %8.3f ms  wall/iter %7.1f ns  memtime/iter w0 %8.1f w4 %8.1f\n", name, ms, ms * 1e6 / iters, (double) c[0] / iters, (double) c[4] / iters);
+	fflush (stdout);
+}
+
 int main (int argc, char** argv)
 {
 	float* d;
@@ -223,6 +275,12 @@ int main (int argc, char** argv)
 	hipMalloc (&d, 256 * 16 * 512 * 4);
 	hipMalloc (&dc, 64);
 	hipMemset (dc, 0, 64);
+	if (argc > 1 && argv[1][0] == 'f') {
+		run_f32<1> ("16 v_mfma_f32_32x32x2_f32 per iteration, one wave per SIMD", 256, d, dc);
+		run_f32<2> ("128 v_pk_fma_f32 per iteration, one wave per SIMD", 256, d, dc);
+		run_f32<3> ("waves 0-3: 16 f32 MFMA | waves 4-7: 128 v_pk_fma_f32 (same SIMDs)", 512, d, dc);
+		return 0;
+	}
 	if (argc > 1) {
 		for (int w : {4, 8}) {
 			run_mix<0, 0, 0> ("36 mfma16 + 4 ds_read_b128", w, d, dc);
