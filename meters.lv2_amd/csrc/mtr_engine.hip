@@ -617,7 +617,10 @@ static int build_plan (mtr_engine* e, uint64_t N, hipStream_t st)
 	const uint64_t min_seg_frames = (uint64_t) 4 * warm_tiles * LT;
 	uint32_t n_segs = e->cfg.tune_segments;
 	if (n_segs == 0) {
-		const uint32_t target_units = 8192;
+		// one-wave workgroups (layouts 4-6): eight per CU are resident, 2048 in all — exactly one round of them keeps the
+		// warm-up overhead of the segments smallest (one stream x 3600 s: 0.29 ms with 2048 segments, 0.37 with 8192);
+		// the four-wave workgroups of layouts 1-3 want more, smaller units
+		const uint32_t target_units = e->layout >= 4 ? 2048 : 8192;
 		n_segs = (target_units + e->cfg.n_streams - 1) / e->cfg.n_streams;
 	}
 	const uint64_t max_segs = std::max<uint64_t> (1, N / std::max<uint64_t> (min_seg_frames, 1));
