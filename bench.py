@@ -299,7 +299,8 @@ def main():
                     q = x.timing_query()
                     c = max(q["calls"], 1)
                     keep = {"tp": x.truepeak() if emeters & M.METER_TRUEPEAK else None,
-                            "o9": x.out9() if emeters & M.METER_EBU else None, "prune": x.prune_stats(), "layout": x.layout()}
+                            "o9": x.out9() if emeters & M.METER_EBU else None, "prune": x.prune_stats(), "refine": x.refine_stats(),
+                            "layout": x.layout()}
                 return q["ms_fused"] / c, q["ms_gate"] / c, q["ms_bank"] / c, wall, keep
 
             def frac(eS, eT, ms):
@@ -311,6 +312,12 @@ def main():
             extra["exact_pruning"] = {"kernel_ms": f, "frac": frac(S, T, f), "tiles_skipped_frac": k["prune"][1] / max(k["prune"][0], 1),
                                       "peaks_identical_to_dense": bool(np.array_equal(k["tp"], peaks)),
                                       "note": "optional (tune_prune=1); not part of `value`"}
+            f, g, _, _, k = timed(S, T, meters, tune_prune=2)
+            extra["exact_pruning_block_refinement"] = {
+                "kernel_ms": f, "frac": frac(S, T, f), "tiles_skipped_frac": k["prune"][1] / max(k["prune"][0], 1),
+                "blocks_completed_frac": k["refine"][1] / max(k["refine"][0], 1),
+                "peaks_identical_to_dense": bool(np.array_equal(k["tp"], peaks)),
+                "note": "optional (tune_prune=2): blocks screened with the first f16 product, completed only near the peak; not part of `value`"}
             f, g, _, _, k = timed(S, T, meters, tune_layout=3)
             rel = np.abs(k["tp"].astype(np.float64) - peaks) / np.maximum(peaks.astype(np.float64), 1e-30)
             extra["f32_valu_interpolator"] = {"kernel": "k_fused2", "kernel_ms": f, "frac": frac(S, T, f),

@@ -76,8 +76,10 @@ typedef struct {
 	                          *     held to the same 2e-6 relative parity bound as layouts 1-3 (tests/test_gpu_layout6.py) */
 	uint32_t tune_fir;       /* interpolator form: 0 = auto (mirror-symmetric), 1 = dense 3 x 48 taps;
 	                          * layout 5 only: 3 = separate f32 tile buffer (first form, one wave per SIMD) */
-	uint32_t tune_prune;     /* 1 = exact true-peak pruning (branch and bound on L1 * max|x|): identical result,
-	                          * data-dependent speed; off by default so the default timing is the dense one */
+	uint32_t tune_prune;     /* 1 = exact true-peak pruning (branch and bound on L1 * max|x| per tile): identical result,
+	                          * data-dependent speed; off by default so the default timing is the dense one.
+	                          * 2 (layout 6) = the same, and inside a tile every 256-frame block is screened with the first of
+	                          * the three f16 products and completed only if it can still hold the maximum: also identical */
 } mtr_config;
 
 /* Per-stream results.  The first nine floats are Ebu_r128_proc's getters in
@@ -221,6 +223,9 @@ int  mtr_engine_timing_enable (mtr_engine* e, int on);
 int  mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, float* ms_bank, uint32_t* calls);
 /* With tune_prune: interpolator tile passes considered / skipped since the engine was created. */
 int  mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped);
+/* With tune_prune = 2 (layout 6): 256-frame channel-blocks screened with the first of the three products / completed
+ * with the other two, since the engine was created. */
+int  mtr_engine_refine_stats (mtr_engine* e, uint64_t* screened, uint64_t* completed);
 /* The kernel layout the engine resolved to (tune_layout = 0 picks one from the meters mask), 1..6. */
 int  mtr_engine_layout (const mtr_engine* e);
 /* K-weighting coefficients a0 a1 a2 b1 b2 c3 c4 at `sample_rate` (Ebu_r128_proc::detect_init,

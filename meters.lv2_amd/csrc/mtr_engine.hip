@@ -133,8 +133,8 @@ struct mtr_engine {
 	DevBuf<float>    fir_pmq;       // [3][24] the same in mirror-symmetric form (ballistics kernel)
 	DevBuf<uint16_t> mfma_a;        // layout 5: A fragments of the MFMA interpolator (mtr_mfma_fir.h)
 	DevBuf<uint16_t> m16_a;         // layout 6: hi / lo A fragments of the f32-grade MFMA interpolator (mtr_mfma16_fir.h)
-	DevBuf<uint32_t> prune_cnt;     // [2] interpolator tile passes considered / skipped
-	uint64_t         prune_tot[2] = { 0, 0 };
+	DevBuf<uint32_t> prune_cnt;     // [4] interpolator tile passes considered / skipped, channel-blocks screened / completed
+	uint64_t         prune_tot[4] = { 0, 0, 0, 0 };
 	float            tpb_w[4];      // w1 w2 w3 g of TruePeakdsp::init
 	Plan             plan;
 	uint32_t         last_n_frag = 0;
@@ -205,8 +205,8 @@ static int upload_consts (mtr_engine* e)
 		for (int i = 0; i < 48; ++i)
 			g[ph - 1][i] = (i < 24) ? tab[24 * ph + i] : tab[24 * (4 - ph) + (47 - i)];
 	if (mtr_fused_upload_taps (&g[0][0]) || mtr_fused2_upload_taps (&g[0][0])) return fail (MTR_ERR_HIP, "hipMemcpyToSymbol c_fir");
-	if (e->fir_g.reserve (144) || e->prune_cnt.reserve (2)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_g");
-	HIPCHK (hipMemset (e->prune_cnt.p, 0, 8));
+	if (e->fir_g.reserve (144) || e->prune_cnt.reserve (4)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_g");
+	HIPCHK (hipMemset (e->prune_cnt.p, 0, 16));
 	HIPCHK (hipMemcpy (e->fir_g.p, g, sizeof (g), hipMemcpyHostToDevice));
 	{
 		// the same taps in the mirror-symmetric form (P, M, Q of mtr_fused2.hip) for the ballistics kernel
@@ -723,7 +723,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.mfma_a = e->layout == 6 ? e->m16_a.p : e->mfma_a.p; fa.mfma_words = pl.mfma_words;
 		fa.fir_form = e->cfg.tune_fir;
 		fa.rotate = e->layout == 3;
-		fa.prune = e->cfg.tune_prune ? 1 : 0;
+		fa.prune = e->cfg.tune_prune > 2 ? 2 : (int) e->cfg.tune_prune;
 		fa.prune_stats = e->prune_cnt.p;
 		const int lrc = e->layout == 6 ? mtr_launch_kwtp16 (e->run, ebu, fa, S * pl.n_segs, st)
 		              : e->layout == 5 ? mtr_launch_kwtp (e->run, ebu, fa, S * pl.n_segs, st)
@@ -1074,17 +1074,33 @@ int mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max
 
 int mtr_engine_layout (const mtr_engine* e) { return e ? e->layout : MTR_ERR_ARG; }
 
-int mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped)
+static int drain_prune_counters (mtr_engine* e)
 {
 	if (!e) return fail (MTR_ERR_ARG, "null engine");
 	int rc = mtr_engine_sync (e);
 	if (rc) return rc;
-	uint32_t h[2];
-	HIPCHK (hipMemcpy (h, e->prune_cnt.p, 8, hipMemcpyDeviceToHost));
-	HIPCHK (hipMemset (e->prune_cnt.p, 0, 8));       // 32-bit device counters are drained into 64-bit totals
-	e->prune_tot[0] += h[0]; e->prune_tot[1] += h[1];
+	uint32_t h[4];
+	HIPCHK (hipMemcpy (h, e->prune_cnt.p, 16, hipMemcpyDeviceToHost));
+	HIPCHK (hipMemset (e->prune_cnt.p, 0, 16));      // 32-bit device counters are drained into 64-bit totals
+	for (int i = 0; i < 4; ++i) e->prune_tot[i] += h[i];
+	return MTR_OK;
+}
+
+int mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped)
+{
+	int rc = drain_prune_counters (e);
+	if (rc) return rc;
 	if (considered) *considered = e->prune_tot[0];
 	if (skipped) *skipped = e->prune_tot[1];
+	return MTR_OK;
+}
+
+int mtr_engine_refine_stats (mtr_engine* e, uint64_t* screened, uint64_t* completed)
+{
+	int rc = drain_prune_counters (e);
+	if (rc) return rc;
+	if (screened) *screened = e->prune_tot[2];
+	if (completed) *completed = e->prune_tot[3];
 	return MTR_OK;
 }
 

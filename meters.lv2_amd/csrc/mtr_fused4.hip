@@ -225,7 +225,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 	m16::AFrag A;
 	A.load (a.mfma_a, lane);
 	float pk_l = 0.f, pk_r = 0.f;                                      // the segment's peaks so far, per lane
-	uint32_t n_done = 0, n_skip = 0;
+	uint32_t n_done = 0, n_skip = 0, n_blk = 0, n_fin = 0;
 
 	// halo of the first tile: the 47 frames before the call behind one zero (segment 0); later segments start with
 	// warm-up tiles, whose own halo is never multiplied.  Lane i < 24 holds positions 2 i and 2 i + 1.
@@ -320,9 +320,10 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		// a channel whose bound cannot beat its peak so far needs no products (the result is unchanged bit for bit).
 		// Only this option needs the maxima and the peaks so far wave-wide, per tile.
 		bool need_l = jj >= 0, need_r = jj >= 0;
+		float tml = 0.f, tmr = 0.f, run_l = 0.f, run_r = 0.f;
 		if (a.prune && jj >= 0) {
-			const float tml = mtrw::max63 (fmaxf (inside ? ml : 0.f, hl)), tmr = mtrw::max63 (fmaxf (inside ? mr : 0.f, hr));
-			const float run_l = mtrw::max63 (pk_l), run_r = mtrw::max63 (pk_r);
+			tml = mtrw::max63 (fmaxf (inside ? ml : 0.f, hl)); tmr = mtrw::max63 (fmaxf (inside ? mr : 0.f, hr));
+			run_l = mtrw::max63 (pk_l); run_r = mtrw::max63 (pk_r);
 			need_l = 2.5684f * 1.002f * tml > run_l;
 			need_r = 2.5684f * 1.002f * tmr > run_r;
 			n_done += 1; n_skip += !(need_l || need_r);
@@ -415,6 +416,54 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 			const int fo = 2 * col8 + kg4;                                   // + r: output frame of register r inside its block
 			m16::BFrag bl, br;
 			m16::f4 yl[3], yr[3];
+			// (the scale of a tile below 2^-97 is clamped and its scaled maximum can sit in f16's subnormals, where the
+			// bound below does not hold: such a tile takes the dense loop)
+			if (a.prune >= 2 && (!need_l || tml * sc_l >= 16384.f) && (!need_r || tmr * sc_r >= 16384.f)) {
+				// Refinement (tune_prune = 2, exact like the tile-level pruning): the first product, Ghi Xhi, for every block.
+				// The other two move an output by at most eps = 2^-10 L1 max |x|: |Xlo| <= 8 = 2^-11 of a scaled maximum
+				// that is >= 2^14, |Glo| <= 2^-11 |G|, one L1 max |x| each.  A block none of whose first-product outputs
+				// comes within eps of the peak this (stream, segment, channel) had reached before the tile cannot hold
+				// the final maximum and is dropped; a block that might gets the remaining twelve MFMAs on the same
+				// accumulators — bit for bit the dense values.  (5 % on eps covers the f32 accumulation order.)
+				const float k15 = (float) (1 << MTR_M16_TAP_SHIFT);
+				const float thr_l = run_l * sc_l * k15 - (2.5684f * 1.05f / 1024.f) * k15 * (tml * sc_l);
+				const float thr_r = run_r * sc_r * k15 - (2.5684f * 1.05f / 1024.f) * k15 * (tmr * sc_r);
+				const int nb = (len + 255) >> 8;
+				for (int b = 0; b < nb; ++b) {
+					const int w = min (128 * b + col8, 8 * CMAX) + kg4;
+					const int lim = len - 256 * b - fo;                          // registers r < lim are outputs of this tile
+					bl.h0 = *reinterpret_cast<const uint4*> (HL + w); bl.h1 = *reinterpret_cast<const uint4*> (HL + w + 16);
+					br.h0 = *reinterpret_cast<const uint4*> (HR + w); br.h1 = *reinterpret_cast<const uint4*> (HR + w + 16);
+					m16::block_first (A, bl.h0, bl.h1, yl);
+					m16::block_first (A, br.h0, br.h1, yr);
+					bool hit_l = false, hit_r = false;
+#pragma unroll
+					for (int p = 0; p < 3; ++p)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							hit_l |= r < lim && fabsf (yl[p][r]) >= thr_l;
+							hit_r |= r < lim && fabsf (yr[p][r]) >= thr_r;
+						}
+					const bool go_l = need_l && __ballot (hit_l) != 0, go_r = need_r && __ballot (hit_r) != 0;
+					n_blk += 2; n_fin += (go_l ? 1 : 0) + (go_r ? 1 : 0);
+					if (go_l) {
+						bl.l0 = *reinterpret_cast<const uint4*> (LL + w); bl.l1 = *reinterpret_cast<const uint4*> (LL + w + 16);
+						m16::block_rest (A, bl.h0, bl.h1, bl.l0, bl.l1, yl);
+#pragma unroll
+						for (int p = 0; p < 3; ++p)
+#pragma unroll
+							for (int r = 0; r < 4; ++r) pl = fmaxf (pl, r < lim ? fabsf (yl[p][r]) : 0.f);
+					}
+					if (go_r) {
+						br.l0 = *reinterpret_cast<const uint4*> (LR + w); br.l1 = *reinterpret_cast<const uint4*> (LR + w + 16);
+						m16::block_rest (A, br.h0, br.h1, br.l0, br.l1, yr);
+#pragma unroll
+						for (int p = 0; p < 3; ++p)
+#pragma unroll
+							for (int r = 0; r < 4; ++r) pr = fmaxf (pr, r < lim ? fabsf (yr[p][r]) : 0.f);
+					}
+				}
+			} else {
 #pragma unroll
 			for (int p = 0; p < 3; ++p) yr[p] = m16::f4{0.f, 0.f, 0.f, 0.f};
 			// word index of this lane's window in block b: 128 b + col8 + kg4.  Full blocks lie inside the arrays; only the
@@ -467,6 +516,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 						}
 				}
 			}
+			}
 			pk_l = fmaxf (pk_l, pl * un_l);                                  // back to the samples' own scale (exact)
 			pk_r = fmaxf (pk_r, pr * un_r);
 		}
@@ -498,6 +548,8 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 	if (a.prune && lane == 0 && a.prune_stats) {
 		atomicAdd (&a.prune_stats[0], n_done);
 		atomicAdd (&a.prune_stats[1], n_skip);
+		atomicAdd (&a.prune_stats[2], n_blk);
+		atomicAdd (&a.prune_stats[3], n_fin);
 	}
 	pk_l = mtrw::max63 (pk_l);
 	pk_r = mtrw::max63 (pk_r);

@@ -45,7 +45,7 @@ struct mtr_fused_args {
 	uint32_t        fir_form;     /* 0 = mirror-symmetric form (120 ops/frame), 1 = dense 3 x 48 taps (144) */
 	uint32_t        rotate;       /* wave-specialised kernel: rotate the loader / K-filter role over the four waves */
 	uint32_t        prune;        /* exact peak pruning: skip the interpolator where L1 * max|x| cannot beat the running peak */
-	uint32_t*       prune_stats;  /* [2] register-tile passes considered / skipped (device counters), may be NULL */
+	uint32_t*       prune_stats;  /* [4] tile passes considered / skipped, channel-blocks screened / completed (device counters), may be NULL */
 	const uint16_t* mfma_a;       /* layout 5: A fragments of the MFMA interpolator, [7][64][8] halves (mtr_mfma_fir.h);
 	                               * layout 6: [12][64][8] hi / lo fragments (mtr_mfma16_fir.h) */
 	uint32_t        mfma_words;   /* layout 5: LDS words per channel of the {hi, lo} sample arrays (multiple of 4) */

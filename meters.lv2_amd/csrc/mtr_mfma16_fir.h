@@ -129,5 +129,29 @@ __device__ __forceinline__ void block (const AFrag& A, const BFrag& B, f4 (&y)[3
 	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 1) * 2 + 1], B.h1, y[p]);
 }
 
+// The same products in two instalments, for the refinement form of exact pruning (tune_prune = 2): block_first is
+// Ghi Xhi alone, block_rest adds Ghi Xlo and Glo Xhi — the MFMAs of block () in the same order on the same accumulators,
+// so first + rest is bit-for-bit block ().
+__device__ __forceinline__ void block_first (const AFrag& A, const uint4& h0, const uint4& h1, f4 (&y)[3])
+{
+#pragma unroll
+	for (int p = 0; p < 3; ++p) y[p] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 0) * 2 + 0], h0, y[p]);
+#pragma unroll
+	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 1) * 2 + 0], h1, y[p]);
+}
+__device__ __forceinline__ void block_rest (const AFrag& A, const uint4& h0, const uint4& h1, const uint4& l0, const uint4& l1, f4 (&y)[3])
+{
+#pragma unroll
+	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 0) * 2 + 0], l0, y[p]);
+#pragma unroll
+	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 1) * 2 + 0], l1, y[p]);
+#pragma unroll
+	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 0) * 2 + 1], h0, y[p]);
+#pragma unroll
+	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 1) * 2 + 1], h1, y[p]);
+}
+
 }  // namespace m16
 #endif

@@ -102,6 +102,7 @@ def _load():
     L.mtr_engine_kmeter_read.argtypes = [vp, u32, u32, vp, vp]
     L.mtr_engine_kmeter_reset.argtypes = [vp]
     L.mtr_engine_prune_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.mtr_engine_refine_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_engine_layout.argtypes = [vp]
     L.mtr_comm_unique_id.argtypes = [vp]
     L.mtr_comm_init.argtypes = [C.POINTER(vp), i32, i32, vp, i32]
@@ -350,6 +351,12 @@ class Engine:
     def prune_stats(self):
         a, b = C.c_uint64(), C.c_uint64()
         _check(lib.mtr_engine_prune_stats(self._h, C.byref(a), C.byref(b)), "prune_stats")
+        return a.value, b.value
+
+    def refine_stats(self):
+        """tune_prune = 2: (channel-blocks screened with the first product, completed with the other two)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib.mtr_engine_refine_stats(self._h, C.byref(a), C.byref(b)), "refine_stats")
         return a.value, b.value
 
     def timing_enable(self, on=True):

@@ -171,6 +171,43 @@ def test_layout6_exact_pruning_changes_nothing_but_time(M):
     assert considered > 0 and skipped > 0.2 * considered          # streams 0 and 3 are mostly prunable
 
 
+def test_layout6_block_refinement_is_bit_identical(M):
+    """tune_prune = 2: every 256-frame block is screened with the first f16 product and completed only when it can
+    still hold the maximum.  Same peaks to the bit, on steady noise (where the tile-level bound never prunes), on a
+    programme with level changes, on tiny and on non-finite samples, EBU + true peak and true peak alone."""
+    import _signals as sig
+    T = 48000 * 6
+    steady = sig.lcg_noise(T, 17, 0.5)
+    prog = (sig.lcg_noise(T, 18, 0.5) * (0.1 + 0.9 * np.abs(np.sin(np.arange(T, dtype=np.float32) / 20000.0)))[:, None]).astype(np.float32)
+    tiny = (sig.lcg_noise(T, 19, 0.5) * np.float32(1e-30)).astype(np.float32)
+    tiny[T // 2:] *= np.float32(1e-9)                                  # below 2^-97: the clamped-scale tiles
+    sine = np.zeros((T, 2), np.float32)
+    n = np.arange(T, dtype=np.float64)
+    sine[:, 0] = (0.7 * np.sin(2 * np.pi * 997.0 / 48000.0 * n)).astype(np.float32)
+    sine[:, 1] = (0.7 * np.sin(2 * np.pi * 11999.0 / 48000.0 * n + 0.3)).astype(np.float32)
+    bad = sig.lcg_noise(T, 20, 0.25)
+    bad[1000, 0] = np.nan
+    bad[T - 5000, 1] = np.inf
+    x = np.stack([steady, prog, tiny, sine, bad])
+    for meters in (M.METER_EBU | M.METER_TRUEPEAK, M.METER_TRUEPEAK):
+        res = {}
+        for prune in (0, 2):
+            for segs in (0, 3):
+                with M.Engine(5, 48000.0, meters, tune_layout=6, tune_prune=prune, tune_segments=segs) as e:
+                    if meters & M.METER_EBU:
+                        e.integr_start()
+                    for a, b in ((0, 77777), (77777, 77777 + 1023), (77777 + 1023, T)):
+                        e.process(x[:, a:b])
+                    res[prune, segs] = (e.truepeak(), e.out9() if meters & M.METER_EBU else None, e.refine_stats())
+        for segs in (0, 3):
+            assert np.array_equal(res[0, segs][0], res[2, segs][0], equal_nan=True), (meters, segs, res[0, segs][0], res[2, segs][0])
+            if meters & M.METER_EBU:
+                assert np.array_equal(res[0, segs][1], res[2, segs][1], equal_nan=True)
+        screened, completed = res[2, 0][2]
+        assert screened > 0 and completed < 0.5 * screened, (screened, completed)
+        assert res[0, 0][2] == (0, 0)
+
+
 def test_layout6_is_the_default_for_true_peak(M):
     with M.Engine(1, 48000.0, M.METER_EBU | M.METER_TRUEPEAK) as e:
         assert e.layout() == 6
