@@ -105,9 +105,8 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 			const float v = (float) out;
 			const float q = v * v;
 			val += omega * (q - val);
-			// `val > mx ? val : mx` (spectrumlv2.c:222) as one v_max_f32: a NaN val loses either way, mx is never NaN.
-			// (By hand: fmaxf () costs a second v_max_f32 that only quiets a signalling NaN mx cannot hold.)
-			asm ("v_max_f32 %0, %0, %1" : "+v"(mx) : "v"(val));
+			// `val > mx ? val : mx` (spectrumlv2.c:222) as one v_max_f32: a NaN val loses either way, mx is never NaN
+			mx = __builtin_fmaxf (mx, val);
 		}
 		__syncthreads ();
 	}

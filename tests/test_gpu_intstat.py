@@ -83,7 +83,7 @@ def test_bitstats_class_switches_and_flushes(M, oracle):
 def test_sigdist_bit_exact_bins(M, oracle):
     S, T = 6, 48000
     x = np.stack([sig.lcg_noise(T, 900 + s, 2.0 ** -s)[:, 0] for s in range(S)])
-    x[1] *= np.float32(1.5)                                  # some samples beyond +-1.2 -> dropped
+    x[1] *= np.float32(3.0)                                  # peaks at 1.5: samples beyond +-1.2 are dropped
     x[2, :] = np.float32(0.5 / 150)                          # 180.5 -> rint ties to even (bin 180)
     x[3, 100] = np.nan
     x[3, 200] = np.inf
