@@ -174,7 +174,23 @@ def main():
                    tune_segments=args.segments, tune_layout=args.layout, tune_fir=args.fir, tune_prune=args.prune)
     eng.integr_start()
     # the job's communicator: RCCL behind the C ABI; on a shared-GPU rehearsal (gloo) the torch fallback reduces
-    comm = None if shared else mdist.make_comm(rank, world, local)
+    comm, collective = None, "torch.distributed (gloo rehearsal)"
+    if not shared or os.environ.get("MTR_BENCH_TRY_RCCL") == "1":    # (the rehearsal can exercise the agreed fallback: RCCL refuses two ranks on one device)
+        try:
+            comm, collective, err = mdist.make_comm(rank, world, local), "RCCL behind the C ABI (mtr_engine_reduce)", None
+        except Exception as ex:                                   # noqa: BLE001 — reported below, never silent
+            err = ex
+        if world > 1:
+            # every rank reduces the same way or none does: one rank on the fallback would leave the others in ncclAllReduce
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm, collective = None, "torch.distributed all_reduce (mtr_comm_init failed on a rank: %s)" % (err or "another rank")
+                print("bench.py: rank %d: %s" % (rank, collective), file=sys.stderr)
+        elif err:
+            raise err
 
     def step():
         if mono:
@@ -227,7 +243,8 @@ def main():
                                    f"(per-GPU shard of BASELINE configs[4]); integration on; "
                                    f"per-step RCCL all-reduce of 2x751 histograms + peaks",
                        "streams_per_gpu": S, "frames_per_stream": T, "sample_rate": fs,
-                       "frames_per_s": frames_job / dt, "parallelism": f"streams sharded x{world}"},
+                       "frames_per_s": frames_job / dt, "parallelism": f"streams sharded x{world}",
+                       "collective": collective},
         }
         layout = eng.layout()
         if tq["calls"] and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
