@@ -10,16 +10,18 @@
 // the same 2e-6 relative bound as the VALU interpolator.
 //
 // One wave per (stream, time segment), workgroup = one wave, no barrier.  Per tile (one 50 ms fragment, <= 64 K frames):
-//   1. the tile has landed in LDS as f32 (LDS-DMA) behind the 48 frames before it; each lane reads its run of
-//      K frames (K even: runs start on even frames, 16-byte reads) and lanes 0..23 the last 48 frames (next halo);
+//   1. the tile is in the lanes' run registers (K frames per lane; K even: runs start on even frames) and lanes 0..23
+//      hold the 48 frames in front of it — loaded by the previous tile's step 6;
 //   2. per channel: max |x| over halo and tile -> a power-of-two scale that puts it in [2^14, 2^15): the f16 halves
 //      then carry 22+ bits at any level, from denormal streams to +/-3e38; an Inf / NaN sample poisons only the
 //      outputs it reaches, and the VALU keeps max |x| (phase 0) exact;
-//   3. the run is written back IN PLACE as f16 hi / lo pair words (four arrays: the tile's f32 image is dead);
+//   3. the run goes to LDS as f16 hi / lo pair words (four arrays, 20 KB: all the LDS the kernel uses);
 //   4. K-filter on the unscaled registers: pass 1 -> DPP scan -> pass 2 (as k_kw: loudness is the same arithmetic);
-//   5. ceil(len / 256) blocks x 2 channels x 18 MFMAs, |max| of the twelve accumulators, last block masked;
-//   6. the halo goes back to LDS as f32, the next tile's DMA is issued over the spent words.
-// Two waves per SIMD (20 KB of LDS each): one computes while the other waits for its tile.
+//   5. the next tile's global loads are issued, straight into the run registers (dead from here on);
+//   6. ceil(len / 256) blocks x 2 channels x 18 MFMAs under which those loads land, |max| of the twelve
+//      accumulators, last block masked.
+// Two waves per SIMD.  REGPF = false (tune_fir = 3) is the first form: the f32 tile staged through LDS by LDS-DMA
+// behind the halo, read back transposed, the words written in place over it, the next DMA issued after the products.
 #include <hip/hip_runtime.h>
 
 #include <utility>
