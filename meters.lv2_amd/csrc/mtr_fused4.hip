@@ -493,7 +493,23 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 			}
 #pragma unroll
 			for (int p = 0; p < 3; ++p) { pr = max3abs (pr, yr[p][0], yr[p][1]); pr = max3abs (pr, yr[p][2], yr[p][3]); }
-			if (len & 255) {
+			if ((len & 255) && (len & 255) <= 128) {
+				// the tile's last block holds at most eight columns per channel (48 kHz: 2400 = 9 x 256 + 96): both channels
+				// share ONE block — columns 0..7 read the left arrays, columns 8..15 the right ones, at the same positions
+				const bool rside = (lane & 8) != 0;
+				const int cc8 = 8 * (lane & 7);
+				const int wm = min (128 * nfull + cc8, 8 * CMAX) + kg4;
+				m16::fetch_b (br, rside ? HR : HL, rside ? LR : LL, wm);
+				m16::block (A, br, yr);
+				const int lim = len - 256 * nfull - (2 * cc8 + kg4);         // registers r < lim are outputs of this tile
+				float pm = 0.f;
+#pragma unroll
+				for (int p = 0; p < 3; ++p)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) pm = fmaxf (pm, r < lim ? fabsf (yr[p][r]) : 0.f);
+				pl = fmaxf (pl, rside ? 0.f : pm);
+				pr = fmaxf (pr, rside ? pm : 0.f);
+			} else if (len & 255) {
 				// the tile's last block: frames past its end belong to the next tile (or do not exist yet)
 				m16::fetch_b (br, HR, LR, wlast);
 				m16::block (A, bl, yl);
