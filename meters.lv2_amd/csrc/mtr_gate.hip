@@ -15,8 +15,8 @@
 //     chronological summation order as addfrags(),
 //   * histogram inserts are integer atomics (order-independent, exact),
 //   * calc_integ / calc_range run once, at the last fragment whose `_div2` counter wraps inside
-//     this call — only that evaluation survives in the reference — serially on one lane so the
-//     float accumulation order of integrate() is the reference's.
+//     this call — only that evaluation survives in the reference — one wave each, walking the
+//     occupied bins in the reference's order so that the float accumulation of integrate() is the reference's.
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -26,47 +26,96 @@
 __device__ __forceinline__ float log10f_cr (float x) { return (float) log10 ((double) x); }
 __device__ __forceinline__ float divf_cr (float a, float b) { return (float) ((double) a / (double) b); }
 
-// Ebu_r128_hist::integrate  ebu_r128_proc.cc:82-102
-__device__ float hist_integrate (const int32_t* h, const float* bin_power, int i)
+// Ebu_r128_hist::integrate / calc_integ / calc_range  (ebu_r128_proc.cc:82-150), wave-cooperative: the 64 lanes of ONE
+// wave call these with the same arguments and get the same (wave-uniform) result.
+//
+// The reference walks all 751 bins serially and the float sum depends on that order.  One lane doing the same is a
+// chain of 751 LDS round trips, five times per stream and call — it was 60 % of this kernel.  But an empty bin adds
+// k * p = +0.0f to a non-negative sum and leaves it bit for bit as it was, so only the occupied bins matter: the wave
+// reads 64 bins at a time, a ballot finds the occupied ones, and those are added in the reference's order (readlane
+// by ascending set bit); the division by ten falls where j wraps, whether or not that century holds a point.
+__device__ float hist_integrate (const int32_t* h, const float* bin_power, int i0, int lane)
 {
-	int   j = i % 100, n = 0;
+	int   n = 0;
 	float s = 0;
-	while (i <= 750) {
-		const int k = h[i++];
-		n += k;
-		s += (float) k * bin_power[j++];
-		if (j == 100) { j = 0; s = divf_cr (s, 10.0f); }
+	for (int c = i0 / 100; c < 8; ++c) {
+		const int lo = max (i0, 100 * c), hi = min (100 * c + 99, 750);
+		for (int b = lo; b <= hi; b += 64) {
+			const int   i = b + lane;
+			const int   k = i <= hi ? h[i] : 0;
+			const float p = i <= hi ? bin_power[i - 100 * c] : 0.f;
+			uint64_t m = __ballot (k != 0);
+			while (m) {
+				const int l = __builtin_ctzll (m);
+				m &= m - 1;
+				const int   kk = __builtin_amdgcn_readlane (k, l);
+				const float pp = __int_as_float (__builtin_amdgcn_readlane (__float_as_int (p), l));
+				n += kk;
+				s += (float) kk * pp;
+			}
+		}
+		if (hi == 100 * c + 99) s = divf_cr (s, 10.0f);          // j reached 100 (:96-100)
 	}
 	return divf_cr (s, (float) n);
 }
 
-__device__ void hist_calc_integ (const int32_t* h, int count, const float* bp, float* vi, float* th)
+__device__ void hist_calc_integ (const int32_t* h, int count, const float* bp, float* vi, float* th, int lane)
 {
-	if (count < 50) { *vi = -200.0f; return; }
-	float s = hist_integrate (h, bp, 0);
-	*th = 10 * log10f_cr (s) - 10.0f;
+	if (count < 50) { if (lane == 0) *vi = -200.0f; return; }
+	float s = hist_integrate (h, bp, 0, lane);
+	const float t = 10 * log10f_cr (s) - 10.0f;
 	int k = (int) (floorf (100 * log10f_cr (s) + 0.5f)) + 600;
 	if (k < 0) k = 0;
-	s = hist_integrate (h, bp, k);
-	*vi = 10 * log10f_cr (s);
+	s = hist_integrate (h, bp, k, lane);
+	if (lane == 0) { *th = t; *vi = 10 * log10f_cr (s); }
 }
 
-__device__ void hist_calc_range (const int32_t* h, int count, const float* bp, float* v0, float* v1, float* th)
+__device__ void hist_calc_range (const int32_t* h, int count, const float* bp, float* v0, float* v1, float* th, int lane)
 {
-	if (count < 20) { *v0 = -200.0f; *v1 = -200.0f; return; }
-	float s = hist_integrate (h, bp, 0);
-	*th = 10 * log10f_cr (s) - 20.0f;
+	if (count < 20) { if (lane == 0) { *v0 = -200.0f; *v1 = -200.0f; } return; }
+	float s = hist_integrate (h, bp, 0, lane);
+	const float t = 10 * log10f_cr (s) - 20.0f;
 	// ebu_r128_proc.cc:141: the 0.5 here is a double
 	int k = (int) (floorf ((float) ((double) (100 * log10f_cr (s)) + 0.5))) + 500;
 	if (k < 0) k = 0;
-	int i, j, n = 0;
-	for (i = k; i <= 750; i++) n += h[i];
+	int n = 0;                                                   // points at or above the threshold: integers, any order
+	for (int i = k + lane; i <= 750; i += 64) n += h[i];
+	for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor (n, d, 64);
 	const float a = 0.10f * n;
 	const float b = 0.95f * n;
-	for (i = k, s = 0; s < a; i++) s += h[i];
-	for (j = 750, s = n; s > b; j--) s -= h[j];
-	*v0 = divf_cr ((float) (i - 701), 10.0f);
-	*v1 = divf_cr ((float) (j - 699), 10.0f);
+	// `for (i = k, s = 0; s < a; i++) s += h[i]` stops behind the first bin that takes the sum to a: an occupied one
+	int i = k;
+	s = 0;
+	for (int base = k; base <= 750 && s < a; base += 64) {
+		const int idx = base + lane;
+		const int kk = idx <= 750 ? h[idx] : 0;
+		uint64_t m = __ballot (kk != 0);
+		while (m && s < a) {
+			const int l = __builtin_ctzll (m);
+			m &= m - 1;
+			s += __builtin_amdgcn_readlane (kk, l);
+			i = base + l + 1;
+		}
+	}
+	// `for (j = 750, s = n; s > b; j--) s -= h[j]` likewise from the top (lane l holds bin base - l: set bits descend)
+	int j = 750;
+	s = n;
+	for (int base = 750; base >= 0 && s > b; base -= 64) {
+		const int idx = base - lane;
+		const int kk = idx >= 0 ? h[idx] : 0;
+		uint64_t m = __ballot (kk != 0);
+		while (m && s > b) {
+			const int l = __builtin_ctzll (m);
+			m &= m - 1;
+			s -= __builtin_amdgcn_readlane (kk, l);
+			j = base - l - 1;
+		}
+	}
+	if (lane == 0) {
+		*th = t;
+		*v0 = divf_cr ((float) (i - 701), 10.0f);
+		*v1 = divf_cr ((float) (j - 699), 10.0f);
+	}
 }
 
 // addfrags  ebu_r128_proc.cc:251-260 on a chronological array: pw[-(n-1) .. 0]
@@ -147,10 +196,11 @@ __global__ __launch_bounds__ (256) void k_gate (const mtr_gate_args a)
 		__syncthreads ();
 
 		if (f_calc >= (int) base && f_calc < (int) base + nf) {
-			if (tid == 0) {
-				hist_calc_integ (sh_hist[0], sh_cnt[0], a.bin_power, &st->integ, &st->integ_thr);
-			} else if (tid == 64) {
-				hist_calc_range (sh_hist[1], sh_cnt[1], a.bin_power, &st->rmin, &st->rmax, &st->rthr);
+			// wave 0 integrates, wave 1 finds the range
+			if (tid < 64) {
+				hist_calc_integ (sh_hist[0], sh_cnt[0], a.bin_power, &st->integ, &st->integ_thr, tid);
+			} else if (tid < 128) {
+				hist_calc_range (sh_hist[1], sh_cnt[1], a.bin_power, &st->rmin, &st->rmax, &st->rthr, tid - 64);
 			}
 		}
 		__syncthreads ();
@@ -317,8 +367,8 @@ __global__ __launch_bounds__ (256) void k_gate_final (const mtr_gate_args a)
 	if (tid < 4) sh_cnt[tid] = (tid == 0) ? st->cnt_M : (tid == 1) ? st->cnt_S : (tid == 2) ? st->err_M : st->err_S;
 	__syncthreads ();
 	if (f_calc >= 0) {
-		if (tid == 0)       hist_calc_integ (sh_hist[0], sh_cnt[0], a.bin_power, &st->integ, &st->integ_thr);
-		else if (tid == 64) hist_calc_range (sh_hist[1], sh_cnt[1], a.bin_power, &st->rmin, &st->rmax, &st->rthr);
+		if (tid < 64)       hist_calc_integ (sh_hist[0], sh_cnt[0], a.bin_power, &st->integ, &st->integ_thr, tid);
+		else if (tid < 128) hist_calc_range (sh_hist[1], sh_cnt[1], a.bin_power, &st->rmin, &st->rmax, &st->rthr, tid - 64);
 	}
 	__syncthreads ();
 	if (tid == 0) {
