@@ -114,8 +114,6 @@ struct mtr_engine {
 	DevBuf<double>   bank_coef, bank_z;
 	DevBuf<float>    bank_val, bank_max;
 	DevBuf<int32_t>  bank_ac;
-	DevBuf<int32_t>  agg_hist;
-	DevBuf<float>    agg_max;
 	DevBuf<mtr_bitstats_state> bim;
 	DevBuf<mtr_sigdist_state>  sdh;
 	DevBuf<mtr_dr14_state>     dr_state;
@@ -382,7 +380,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	if (e->own_stream) (void) hipStreamDestroy (e->own_stream);
 	if (e->xs_event) (void) hipEventDestroy (e->xs_event);
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
-	e->agg_hist.release (); e->agg_max.release (); e->fir_g.release (); e->mfma_a.release (); e->m16_a.release ();
+	e->fir_g.release (); e->mfma_a.release (); e->m16_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
 	e->dr_state.release (); e->dr_hist.release (); e->dr_sum.release (); e->dr_peak.release ();
 	e->km_state.release (); e->km_piece.release (); e->km_max.release ();
@@ -998,10 +996,7 @@ int mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, v
 {
 	if (!e || !d_hist || !d_max) return fail (MTR_ERR_ARG, "mtr_engine_aggregate_device: null argument");
 	HIPCHK (hipSetDevice (e->cfg.device));
-	const uint32_t np = mtr_aggregate_parts (e->cfg.n_streams);
-	if (e->agg_hist.reserve ((size_t) np * 2 * MTR_HIST_LEN) || e->agg_max.reserve ((size_t) np * 4))
-		return fail (MTR_ERR_NOMEM, "hipMalloc aggregate scratch");
-	if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, e->agg_hist.p, e->agg_max.p, d_hist, d_max, hip_stream))
+	if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, d_hist, d_max, hip_stream))
 		return fail (MTR_ERR_HIP, "k_aggregate launch");
 	return MTR_OK;
 }

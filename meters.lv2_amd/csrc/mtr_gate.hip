@@ -471,54 +471,56 @@ int mtr_launch_state_init (mtr_stream_state* st, int32_t* hist, uint32_t n_strea
 
 // ---- cross-stream aggregate (input of the multi-GPU all-reduce) ---------------------------------
 
-#define AGG_SPB 64   /* streams per block of the first pass */
+#define AGG_SPB 8    /* streams per block */
 
-// pass 1: block b sums the histograms of streams [b*64, b*64+64) and takes their maxima
-__global__ __launch_bounds__ (256) void k_aggregate1 (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
-                                                      int32_t* part_hist, float* part_max)
+__device__ __forceinline__ void atomic_max_f32 (float* p, float v)
 {
-	const uint32_t s0 = blockIdx.x * AGG_SPB, s1 = min (s0 + AGG_SPB, n_streams);
+	int* const ip = reinterpret_cast<int*> (p);
+	int old = *ip;
+	while (v > __int_as_float (old)) {
+		const int seen = atomicCAS (ip, old, __float_as_int (v));
+		if (seen == old) break;
+		old = seen;
+	}
+}
+
+__global__ void k_aggregate_init (int32_t* d_hist, float* d_max)
+{
+	for (int bin = threadIdx.x; bin < 2 * MTR_HIST_LEN; bin += blockDim.x) d_hist[bin] = 0;
+	if (threadIdx.x < 4) d_max[threadIdx.x] = (threadIdx.x < 2) ? 0.f : -200.f;
+}
+
+// Block b folds streams [8 b, 8 b + 8) — eight independent loads per bin — and adds what is not zero to the job's
+// histograms with integer atomics (most of a stream's 1502 bins are empty); maxima by compare-and-swap.  Integer sums and
+// maxima do not depend on the order: the result is deterministic.  (The first version summed 64 streams per block
+// serially and folded the partials in a second pass: 0.11 ms of latency for 49 MB.)
+__global__ __launch_bounds__ (256) void k_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
+                                                     int32_t* d_hist, float* d_max)
+{
+	const uint32_t s0 = blockIdx.x * AGG_SPB;
+	const int ns = (int) min ((uint32_t) AGG_SPB, n_streams - s0);
+	const int32_t* const h0 = hist + (size_t) s0 * 2 * MTR_HIST_LEN;
 	for (int bin = threadIdx.x; bin < 2 * MTR_HIST_LEN; bin += 256) {
 		int32_t acc = 0;
-		for (uint32_t s = s0; s < s1; ++s) acc += hist[(size_t) s * 2 * MTR_HIST_LEN + bin];
-		part_hist[(size_t) blockIdx.x * 2 * MTR_HIST_LEN + bin] = acc;
+#pragma unroll
+		for (int i = 0; i < AGG_SPB; ++i) acc += i < ns ? h0[(size_t) i * 2 * MTR_HIST_LEN + bin] : 0;
+		if (acc) atomicAdd (&d_hist[bin], acc);
 	}
 	if (threadIdx.x < 4) {
 		float m = (threadIdx.x < 2) ? 0.f : -200.f;
-		for (uint32_t s = s0; s < s1; ++s) {
-			const float v = threadIdx.x == 0 ? st[s].tp_hold[0] : threadIdx.x == 1 ? st[s].tp_hold[1]
-			              : threadIdx.x == 2 ? st[s].max_M : st[s].max_S;
+		for (int i = 0; i < ns; ++i) {
+			const mtr_stream_state& p = st[s0 + i];
+			const float v = threadIdx.x == 0 ? p.tp_hold[0] : threadIdx.x == 1 ? p.tp_hold[1] : threadIdx.x == 2 ? p.max_M : p.max_S;
 			m = v > m ? v : m;
 		}
-		part_max[blockIdx.x * 4 + threadIdx.x] = m;
+		atomic_max_f32 (&d_max[threadIdx.x], m);
 	}
 }
 
-// pass 2: fold the per-block partials (deterministic, no atomics)
-__global__ void k_aggregate2 (const int32_t* part_hist, const float* part_max, uint32_t n_part,
-                              int32_t* d_hist, float* d_max)
+int mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams, int32_t* d_hist, float* d_max, void* stream)
 {
-	const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-	if (bin < 2 * MTR_HIST_LEN) {
-		int32_t acc = 0;
-		for (uint32_t b = 0; b < n_part; ++b) acc += part_hist[(size_t) b * 2 * MTR_HIST_LEN + bin];
-		d_hist[bin] = acc;
-	}
-	if (blockIdx.x == 0 && threadIdx.x < 4) {
-		float m = (threadIdx.x < 2) ? 0.f : -200.f;
-		for (uint32_t b = 0; b < n_part; ++b) { const float v = part_max[b * 4 + threadIdx.x]; m = v > m ? v : m; }
-		d_max[threadIdx.x] = m;
-	}
-}
-
-uint32_t mtr_aggregate_parts (uint32_t n_streams) { return (n_streams + AGG_SPB - 1) / AGG_SPB; }
-
-int mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
-                          int32_t* part_hist, float* part_max, int32_t* d_hist, float* d_max, void* stream)
-{
-	const uint32_t np = mtr_aggregate_parts (n_streams);
-	hipLaunchKernelGGL (k_aggregate1, dim3 (np), dim3 (256), 0, (hipStream_t) stream, st, hist, n_streams, part_hist, part_max);
-	hipLaunchKernelGGL (k_aggregate2, dim3 ((2 * MTR_HIST_LEN + 255) / 256), dim3 (256), 0, (hipStream_t) stream,
-	                    part_hist, part_max, np, d_hist, d_max);
+	hipLaunchKernelGGL (k_aggregate_init, dim3 (1), dim3 (256), 0, (hipStream_t) stream, d_hist, d_max);
+	hipLaunchKernelGGL (k_aggregate, dim3 ((n_streams + AGG_SPB - 1) / AGG_SPB), dim3 (256), 0, (hipStream_t) stream,
+	                    st, hist, n_streams, d_hist, d_max);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }

@@ -181,9 +181,7 @@ int  mtr_launch_sigdist (const float* audio, uint64_t stride, uint64_t n_frames,
                          uint32_t n_streams, void* stream);
 int  mtr_launch_history_mono (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
                               float* hist_out, uint32_t n_streams, void* stream);
-uint32_t mtr_aggregate_parts (uint32_t n_streams);
-int  mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams,
-                           int32_t* part_hist, float* part_max, int32_t* d_hist, float* d_max, void* stream);
+int  mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams, int32_t* d_hist, float* d_max, void* stream);
 int  mtr_launch_synth (float* d_audio, uint32_t n_streams, uint64_t n_frames, uint64_t stride,
                        uint32_t seed, float fs, int kind, void* stream);
 #endif
