@@ -1,0 +1,75 @@
+"""Seeded shape fuzz of the default EBU R128 + true-peak path against the oracle.
+
+The hand-picked cases of test_gpu_parity.py / test_gpu_layout6.py fix the sizes that matter by construction (tile and
+block boundaries, LV2-sized calls, the rates of the reference's own plugins); this file draws the rest: sample rate,
+number of streams, stream length, how the stream is cut into process() calls, time segments, exact pruning level, and
+programme-like level changes — 96 + 32 seeded cases, each checked per stream with the tolerances stated at the top of
+test_gpu_parity.py (M / S 1e-3 dB, true peak 2e-6 relative, fragment powers 2e-5 relative, histograms <= 2 moved points)."""
+import numpy as np
+import pytest
+
+import _signals as sig
+from test_gpu_parity import _check_ebu, M  # noqa: F401  (M: the module fixture)
+
+pytestmark = pytest.mark.gpu
+
+RATES = (44100.0, 48000.0, 88200.0, 96000.0, 192000.0)
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    fs = RATES[int(rng.integers(len(RATES)))]
+    S = int(rng.integers(1, 9))
+    T = int(rng.integers(100, int(2.6 * fs))) if seed % 4 else int(rng.integers(100, 6000))   # up to ~50 fragments; every fourth case shorter than three
+    ncall = int(rng.integers(1, 6))
+    cuts = np.sort(rng.integers(1, T, size=ncall - 1)) if ncall > 1 else np.array([], np.int64)
+    calls = np.diff(np.concatenate([[0], cuts, [T]])).astype(int)
+    calls = [int(c) for c in calls if c > 0]
+    x = np.empty((S, T, 2), np.float32)
+    for s in range(S):
+        n = sig.lcg_noise(T, 31 * seed + s, float(rng.uniform(0.05, 0.9)))
+        # two or three level steps and a tone on one channel: peaks move, pruning gets something to do
+        env = np.ones(T, np.float32)
+        for _ in range(int(rng.integers(0, 4))):
+            a = int(rng.integers(0, T))
+            env[a:] *= np.float32(rng.choice([0.125, 0.5, 2.0]))
+        n *= env[:, None]
+        t = np.arange(T, dtype=np.float64) / fs
+        n[:, s & 1] += (0.3 * np.sin(2 * np.pi * float(rng.uniform(50.0, 0.45 * fs)) * t)).astype(np.float32)
+        x[s] = n
+    kw = dict(tune_segments=int(rng.choice([0, 0, 2, 5])), tune_prune=int(rng.choice([0, 1, 2])))
+    return fs, x, calls, kw
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_fuzzed_shapes_against_oracle(M, oracle, seed):  # noqa: F811
+    fs, x, calls, kw = _case(seed)
+    S, T = x.shape[0], x.shape[1]
+    with M.Engine(S, fs, M.METER_EBU | M.METER_TRUEPEAK, **kw) as e:
+        assert e.layout() == 6
+        e.integr_start()
+        pos, frags = 0, []
+        for n in calls:
+            e.process(x[:, pos:pos + n])
+            frags.append(e.fragment_powers())
+            pos += n
+        out9, tp = e.out9(), e.truepeak()
+        hm, hs = e.histograms()
+        frag = np.concatenate(frags, 1)
+    for s in range(S):
+        o = oracle.ebu(x[s], fs, 1024, want_frag=True)
+        _check_ebu(out9[s], (hm[s], hs[s]), o["out9"], (o["hist_M"], o["hist_S"]), None, frag[s], o["frag_power"])
+        assert np.allclose(tp[s], oracle.tp(x[s], fs, 4096), rtol=2e-6), (seed, s, fs, calls, kw, tp[s])
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_fuzzed_truepeak_only(M, oracle, seed):  # noqa: F811
+    fs, x, calls, kw = _case(100 + seed)
+    with M.Engine(x.shape[0], fs, M.METER_TRUEPEAK, **kw) as e:
+        pos = 0
+        for n in calls:
+            e.process(x[:, pos:pos + n])
+            pos += n
+        tp = e.truepeak()
+    for s in range(x.shape[0]):
+        assert np.allclose(tp[s], oracle.tp(x[s], fs, 4096), rtol=2e-6), (seed, s, fs, calls, kw)
