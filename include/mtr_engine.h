@@ -132,6 +132,10 @@ int  mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_fr
 /* n_streams == 1, planar host channels — the shape an LV2 run() hands over
  * (src/meters.cc:298-299: one float* per port, n_samples frames). */
 int  mtr_engine_process_planar_host (mtr_engine* e, const float* const* channels, uint32_t n_frames);
+/* Before the first block (an LV2 instantiate / activate): one silent block of `max_block_frames` through the engine and
+ * a full reset — staging buffers, the engine's stream and the kernels' code objects then exist, and the first run() of the
+ * host's audio thread costs what every later one does (tests/test_lv2_latency.py) instead of several milliseconds. */
+int  mtr_engine_prepare_host (mtr_engine* e, uint32_t max_block_frames);
 
 /* Wait for everything queued by process calls. */
 int  mtr_engine_sync (mtr_engine* e);

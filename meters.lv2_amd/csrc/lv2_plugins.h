@@ -15,6 +15,18 @@
  * leaving the last good values there, so a host or GUI can tell "no measurement" from "unchanged level".  Audio is
  * still passed through. */
 #define MTR_LV2_NO_DATA ((float) NAN)
+/* block size the engine is warmed up for at instantiate (mtr_engine_prepare_host): larger blocks still work, the first
+ * one of a larger size pays for its staging buffer */
+#define MTR_LV2_MAX_BLOCK 8192u
+/* an engine for one plugin instance, warmed up: what run () does first must not be the allocation and module loading */
+static inline int lv2_engine_open (const mtr_config* cfg, mtr_engine** out)
+{
+	int rc = mtr_engine_create (cfg, out);
+	if (rc != MTR_OK) return rc;
+	rc = mtr_engine_prepare_host (*out, MTR_LV2_MAX_BLOCK);
+	if (rc != MTR_OK) { mtr_engine_destroy (*out); *out = NULL; }
+	return rc;
+}
 static inline int lv2_engine_ok (int rc, int* failing, const char* who)
 {
 	if (rc == MTR_OK) { *failing = 0; return 1; }

@@ -629,15 +629,17 @@ static int build_plan (mtr_engine* e, uint64_t N, hipStream_t st)
 	for (uint32_t q = 1; q < n_segs; ++q)
 		if ((uint64_t) ts[sg[q]] < (uint64_t) warm_tiles * LT) return fail (MTR_ERR_ARG, "internal: segment shorter than its warm-up");
 
-	if (e->tile_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_tiles, 1))
-	    || e->frag_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_frag, 1)))
+	// (with head-room: an LV2 host's blocks see a fragment end in some calls and none in others, and a buffer that grows
+	// by one word then is a hipMalloc — 0.3 ms — in the audio thread)
+	if (e->tile_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_tiles, 16))
+	    || e->frag_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_frag, 16)))
 		return fail (MTR_ERR_NOMEM, "hipMalloc plan buffers");
 	// the next slot of the ring; its previous contents were last read PLAN_SLOTS plans ago
 	const int slot = (e->plan_cur + 1) % PLAN_SLOTS;
 	PlanSlot& ps = e->plan_slot[slot];
 	if (ps.pending) { HIPCHK (hipEventSynchronize (ps.done)); ps.pending = false; }
 	const size_t words = ts.size () + sg.size () + ft.size ();
-	if (ps.dev.reserve (words) || ps.pin.reserve (words)) return fail (MTR_ERR_NOMEM, "plan slot");
+	if (ps.dev.reserve (std::max<size_t> (words, 256)) || ps.pin.reserve (std::max<size_t> (words, 256))) return fail (MTR_ERR_NOMEM, "plan slot");
 	if (!ps.done) HIPCHK (hipEventCreateWithFlags (&ps.done, hipEventDisableTiming));
 	memcpy (ps.pin.p, ts.data (), ts.size () * 4);
 	memcpy (ps.pin.p + ts.size (), sg.data (), sg.size () * 4);
@@ -885,6 +887,20 @@ int mtr_engine_process_planar_host (mtr_engine* e, const float* const* ch, uint3
 	HIPCHK (hipStreamSynchronize (st));
 	e->snap_valid = true;
 	return MTR_OK;
+}
+
+int mtr_engine_prepare_host (mtr_engine* e, uint32_t max_block_frames)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	if (e->cfg.n_streams != 1) return fail (MTR_ERR_ARG, "mtr_engine_prepare_host is for the n_streams == 1 (LV2) path");
+	if (max_block_frames == 0) return MTR_OK;
+	// one silent block of the largest size: page-locked staging, device buffers, the engine's stream and every kernel's
+	// code object exist afterwards (a first launch loads the module: milliseconds); then back to the state of a new engine
+	std::vector<float> zeros (max_block_frames, 0.f);
+	const float* ch[2] = { zeros.data (), zeros.data () };
+	int rc = mtr_engine_process_planar_host (e, ch, max_block_frames);
+	if (rc) return rc;
+	return mtr_engine_reset (e);
 }
 
 int mtr_engine_sync (mtr_engine* e)
