@@ -83,7 +83,7 @@ def kernel_sha():
     """Hash of the sources of the dominant kernel: the committed PMC traffic figure is valid for exactly this code."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("mtr_fused4.hip", "mtr_mfma16_fir.h", "mtr_wave.h"):
+    for f in ("mtr_fused4.hip", "mtr_mfma16_fir.h", "mtr_wave.h", "mtr_kw_steps.h"):
         h.update(open(os.path.join(ROOT, "meters.lv2_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

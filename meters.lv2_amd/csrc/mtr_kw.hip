@@ -20,26 +20,15 @@
 // slot offset 1, so the 16-byte source alignment of global_load_lds_dwordx4 always holds.
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "mtr_internal.h"
 #include "mtr_wave.h"
+#include "mtr_kw_steps.h"
 
 namespace {
 
 __device__ __forceinline__ v2f scrub (v2f v) { return v2f{isfinite (v.x) ? v.x : 0.f, isfinite (v.y) ? v.y : 0.f}; }
-
-// One K-weighting step for both channels (ebu_r128_proc.cc:321-326); same association as k_fused2.
-#define KW_STEP(p, y)                                   \
-	{                                                   \
-		v2f t_ = (p) + 1e-15f;                          \
-		t_ = t_ - b2 * z2;                              \
-		const v2f x_ = t_ - b1 * z1;                    \
-		v2f u_ = a1 * z1;                               \
-		u_ = u_ + a2 * z2;                              \
-		u_ = u_ - c4 * z4;                              \
-		u_ = u_ - c3 * z3;                              \
-		y = a0 * x_ + u_;                               \
-		z2 = z1; z1 = x_; z4 += z3; z3 += y;            \
-	}
 
 template <int K>
 __global__ __launch_bounds__ (64) void k_kw (const mtr_fused_args a)
@@ -144,13 +133,25 @@ __global__ __launch_bounds__ (64) void k_kw (const mtr_fused_args a)
 			// pass 2: from the true start state (end state of the lane to the left), sum y^2
 			z1 = mtrw::from_left (z1); z2 = mtrw::from_left (z2); z3 = mtrw::from_left (z3); z4 = mtrw::from_left (z4);
 			if (lane == 0) { z1 = k1; z2 = k2; z3 = k3; z4 = k4; }
+			// frames 0 .. K - 2 in hand-scheduled pairs (mtr_kw_steps.h): one lane per tile has a partial run — steps
+			// n < rl_last run in the lanes up to and including it, the others in the lanes before it; frame K - 1 (K is odd)
+			// in the lanes whose run is whole
+			const int last_l = (len - 1) / K, rl_last = len - last_l * K;
+			const uint64_t upto = __ballot (lane <= last_l), before = __ballot (lane < last_l);
+			const v2f A0 = v2f{a0, a0}, A1 = v2f{a1, a1}, A2 = v2f{a2, a2}, B1 = v2f{b1, b1}, B2 = v2f{b2, b2}, C3 = v2f{c3, c3}, C4 = v2f{c4, c4};
+			const v2f eps2 = v2f{1e-15f, 1e-15f};
 			v2f sj = 0;
-#pragma unroll
-			for (int n = 0; n < K; ++n) {
-				if (n < rl) { v2f y; KW_STEP (x[n], y); sj += y * y; }
+			[&]<int... P> (std::integer_sequence<int, P...>) {
+				(kw_pair<2 * P> (x[2 * P], x[2 * P + 1], z1, z2, z3, z4, sj, A0, A1, A2, B1, B2, C3, C4, eps2, upto, before, rl_last), ...);
+			} (std::make_integer_sequence<int, (K - 1) / 2> {});
+			if ((rl_last & 1) && rl_last < K) {
+				// the partial lane stopped between the two steps of a pair: its shelving states sit swapped
+				const v2f w1 = mtrw::pick (z1, last_l), w2 = mtrw::pick (z2, last_l);
+				if (lane == last_l) { z1 = w2; z2 = w1; }
 			}
-			const float sl = mtrw::sum63 (sj.x), sr = mtrw::sum63 (sj.y);
-			if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = a.gain_l * sl + a.gain_r * sr;
+			if (rl == K) { v2f y; KW_STEP (x[K - 1], y); sj += y * y; }
+			const float pw = mtrw::sum63 (a.gain_l * sj.x + a.gain_r * sj.y);
+			if (lane == 0) a.tile_power[(size_t) s * a.n_tiles + jt0 + jj] = pw;
 			const int last = (len - 1) / K;                    // the lane holding the state after the last frame
 			k1 = mtrw::pick (z1, last); k2 = mtrw::pick (z2, last); k3 = mtrw::pick (z3, last); k4 = mtrw::pick (z4, last);
 		}
