@@ -3,7 +3,7 @@
 The hand-picked cases of test_gpu_parity.py / test_gpu_layout6.py fix the sizes that matter by construction (tile and
 block boundaries, LV2-sized calls, the rates of the reference's own plugins); this file draws the rest: sample rate,
 number of streams, stream length, how the stream is cut into process() calls, time segments, exact pruning level, and
-programme-like level changes — 96 + 32 seeded cases, each checked per stream with the tolerances stated at the top of
+programme-like level changes — 96 + 32 + 32 seeded cases, each checked per stream with the tolerances stated at the top of
 test_gpu_parity.py (M / S 1e-3 dB, true peak 2e-6 relative, fragment powers 2e-5 relative, histograms <= 2 moved points)."""
 import numpy as np
 import pytest
@@ -73,3 +73,24 @@ def test_fuzzed_truepeak_only(M, oracle, seed):  # noqa: F811
         tp = e.truepeak()
     for s in range(x.shape[0]):
         assert np.allclose(tp[s], oracle.tp(x[s], fs, 4096), rtol=2e-6), (seed, s, fs, calls, kw)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_fuzzed_ebu_only(M, oracle, seed):  # noqa: F811
+    """k_kw, the K-weighting-only kernel (layout 4): its own tiling (39-frame runs through LDS) and pass 2."""
+    fs, x, calls, kw = _case(200 + seed)
+    S = x.shape[0]
+    with M.Engine(S, fs, M.METER_EBU, tune_segments=kw["tune_segments"]) as e:
+        assert e.layout() == 4
+        e.integr_start()
+        pos, frags = 0, []
+        for n in calls:
+            e.process(x[:, pos:pos + n])
+            frags.append(e.fragment_powers())
+            pos += n
+        out9 = e.out9()
+        hm, hs = e.histograms()
+        frag = np.concatenate(frags, 1)
+    for s in range(S):
+        o = oracle.ebu(x[s], fs, 1024, want_frag=True)
+        _check_ebu(out9[s], (hm[s], hs[s]), o["out9"], (o["hist_M"], o["hist_S"]), None, frag[s], o["frag_power"])
