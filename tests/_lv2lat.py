@@ -73,4 +73,5 @@ def run_latency(host, name, n, blocks=300, warm=30, ui=False):
             t[i - warm] = dt
     inst.cleanup()
     return {"median_us": float(np.median(t) * 1e6), "p99_us": float(np.quantile(t, 0.99) * 1e6),
-            "max_us": float(t.max() * 1e6), "budget_us": n / 48000.0 * 1e6}
+            "max_us": float(t.max() * 1e6), "budget_us": n / 48000.0 * 1e6,
+            "first10_max_us": float(t[:10].max() * 1e6), "over_budget": int((t > n / 48000.0).sum())}
