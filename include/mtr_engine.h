@@ -61,25 +61,28 @@ typedef struct {
 	float    sample_rate;    /* Hz; reference: instantiate()'s `rate` (src/meters.cc:194) */
 	int32_t  device;         /* HIP device ordinal */
 	uint32_t max_frames;     /* largest n_frames a process call will carry (scratch sizing); 0 = grow on demand */
-	uint32_t tune_run;       /* frames per lane run of the fused kernel: 0 = auto, else 13, 39 (19: layouts 4 and 5 only; 38: layout 6 only) */
-	uint32_t tune_segments;  /* time segments per stream per call: 0 = auto */
-	uint32_t tune_layout;    /* 0 = auto, 1 = one wave per stream segment, 2 = wave-specialised workgroups (run 39),
-	                          * 3 = as 2 with the loader / K-filter role rotating over the four waves: the exact-f32 VALU
-	                          *     interpolator, bit-for-bit an fmaf chain over the reference's taps (round 1's default),
+	uint32_t tune_run;       /* frames per lane run of the wave-per-segment kernels: 0 = auto, 39 (layouts 3, 4), 19 (layout 4), 38 (layouts 6, 7) */
+	uint32_t tune_segments;  /* time segments per stream per call: 0 = auto (layout 7: also forces the lane = segment kernel
+	                          * onto every call it can serve, however small the batch) */
+	uint32_t tune_layout;    /* 0 = auto,
+	                          * 3 = the exact-f32 VALU interpolator, bit-for-bit an fmaf chain over the reference's taps
+	                          *     (round 1's default; the cross-check of the matrix-pipe paths),
 	                          * 4 = the K-weighting-only kernel (EBU without TRUEPEAK; auto for that mask),
-	                          * 5 = OPT-IN: layout 4 plus the interpolator on the matrix pipe (f16-split samples, f16 taps,
-	                          *     f32 accumulation; needs TRUEPEAK, run 19 or 39).  True peaks within 0.0056 dB of the
-	                          *     f32 interpolator of layouts 1-3 — inside the +-0.01 dB tolerance, not bit-identical,
-	                          * 6 = layout 4 plus the interpolator on the matrix pipe AT F32 GRADE (auto wherever TRUEPEAK is
-	                          *     asked for; run 38): samples and taps as two f16 halves each, three partial products, f32
+	                          * 6 = K-weighting + the interpolator on the matrix pipe AT F32 GRADE, one wave per (stream, time
+	                          *     segment): samples and taps as two f16 halves each, three partial products, f32
 	                          *     accumulation — within 3e-7 relative of a float64 interpolator, like the f32 chain itself;
-	                          *     held to the same 2e-6 relative parity bound as layouts 1-3 (tests/test_gpu_layout6.py) */
-	uint32_t tune_fir;       /* interpolator form: 0 = auto (mirror-symmetric), 1 = dense 3 x 48 taps;
-	                          * layout 5 only: 3 = separate f32 tile buffer (first form, one wave per SIMD) */
+	                          *     held to the same 2e-6 relative parity bound as layout 3 (tests/test_gpu_layout6.py),
+	                          * 7 = (auto wherever TRUEPEAK is asked for) layout 6, and for every call that fits it — a batch
+	                          *     big enough to fill the chip's lanes, starting on a 50 ms fragment boundary, 16-frame
+	                          *     fragments, 16-byte aligned streams — the same arithmetic with LANE = TIME SEGMENT
+	                          *     (mtr_seg.hip): whole fragments through that kernel, the rest of the call through layout 6.
+	                          * Layouts 1, 2 and 5 of earlier versions no longer exist: MTR_ERR_ARG. */
+	uint32_t tune_fir;       /* layout 3 only: 0 = mirror-symmetric form (120 ops / frame), 1 = dense 3 x 48 taps */
 	uint32_t tune_prune;     /* 1 = exact true-peak pruning (branch and bound on L1 * max|x| per tile): identical result,
 	                          * data-dependent speed; off by default so the default timing is the dense one.
 	                          * 2 (layout 6) = the same, and inside a tile every 256-frame block is screened with the first of
-	                          * the three f16 products and completed only if it can still hold the maximum: also identical */
+	                          * the three f16 products and completed only if it can still hold the maximum: also identical.
+	                          * (Pruning is a layout 6 feature: with tune_prune set, layout 7 is not used.) */
 } mtr_config;
 
 /* Per-stream results.  The first nine floats are Ebu_r128_proc's getters in
@@ -230,8 +233,11 @@ int  mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skip
 /* With tune_prune = 2 (layout 6): 256-frame channel-blocks screened with the first of the three products / completed
  * with the other two, since the engine was created. */
 int  mtr_engine_refine_stats (mtr_engine* e, uint64_t* screened, uint64_t* completed);
-/* The kernel layout the engine resolved to (tune_layout = 0 picks one from the meters mask), 1..6. */
+/* The kernel layout the engine resolved to (tune_layout = 0 picks one from the meters mask): 3, 4, 6 or 7. */
 int  mtr_engine_layout (const mtr_engine* e);
+/* Layout 7: process calls whose whole fragments went through the lane = time segment kernel, and the frames per stream
+ * it covered, since the engine was created (the calls that did not fit it ran layout 6). */
+int  mtr_engine_seg_stats (mtr_engine* e, uint64_t* calls, uint64_t* frames_per_stream);
 /* K-weighting coefficients a0 a1 a2 b1 b2 c3 c4 at `sample_rate` (Ebu_r128_proc::detect_init,
  * ebumeter/ebu_r128_proc.cc:263-293) */
 int  mtr_kweight_coef (float sample_rate, float* out7);

@@ -76,14 +76,18 @@ struct Plan {
 	uint64_t n_frames = 0;
 	uint32_t frcnt_in = 0;      // frames left in the open fragment when the call starts
 	uint32_t frcnt_out = 0;
-	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0, buf_slots = 0, kw_slots = 0, mfma_words = 0;
+	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0, buf_slots = 0, kw_slots = 0;
+	uint32_t body_tiles = 0;    // whole-fragment tiles in front (the lane = segment kernel's part of the call), 0 = none
 	bool     valid = false;
 };
 
 struct mtr_engine {
 	mtr_config cfg;
 	int      run = 39;            // K: frames per lane run
-	int      layout = 2;          // 1 = wave per segment (mtr_fused.hip), 2 = wave-specialised (mtr_fused2.hip)
+	int      layout = 6;          // 3 = exact-f32 VALU interpolator (mtr_fused2.hip), 4 = k_kw, 6 = k_kwtp16 (+ 7: k_seg for the calls it fits)
+	bool     seg_ok = false;      // layout 7: calls that fit go through k_seg (mtr_seg.hip), the rest through k_kwtp16
+	uint32_t seg_slots = 1024;    // resident k_seg waves: one per SIMD
+	uint64_t seg_calls = 0, seg_frames = 0;
 	uint32_t fragm = 0;           // frames per 50 ms fragment
 	uint32_t frcnt = 0;           // frames remaining in the open fragment (all streams in lock step)
 	bool     integr = false;
@@ -102,6 +106,7 @@ struct mtr_engine {
 	const uint32_t*  tile_start = nullptr;   // into plan_slot[plan_cur].dev
 	const uint32_t*  seg_tile = nullptr;
 	const uint32_t*  frag_tile = nullptr;
+	const uint32_t*  tail_seg = nullptr;     // {first tile behind the k_seg body, n_tiles}: the one segment of the k_kwtp16 launch that finishes such a call
 	// n_streams = 1 host path (the shape of an LV2 run ()): own stream, page-locked staging, and ONE synchronisation per
 	// block — the state (and the bank's levels) come back with the same wait and serve the result getters
 	hipStream_t      own_stream = nullptr;
@@ -129,8 +134,7 @@ struct mtr_engine {
 	float                      km_fall = 0.f;
 	DevBuf<float>    fir_g;         // [3][48] taps in device memory
 	DevBuf<float>    fir_pmq;       // [3][24] the same in mirror-symmetric form (ballistics kernel)
-	DevBuf<uint16_t> mfma_a;        // layout 5: A fragments of the MFMA interpolator (mtr_mfma_fir.h)
-	DevBuf<uint16_t> m16_a;         // layout 6: hi / lo A fragments of the f32-grade MFMA interpolator (mtr_mfma16_fir.h)
+	DevBuf<uint16_t> m16_a;         // layouts 6, 7: hi / lo A fragments of the f32-grade MFMA interpolator (mtr_mfma16_fir.h)
 	DevBuf<uint32_t> prune_cnt;     // [4] interpolator tile passes considered / skipped, channel-blocks screened / completed
 	uint64_t         prune_tot[4] = { 0, 0, 0, 0 };
 	float            tpb_w[4];      // w1 w2 w3 g of TruePeakdsp::init
@@ -202,7 +206,7 @@ static int upload_consts (mtr_engine* e)
 	for (int ph = 1; ph <= 3; ++ph)
 		for (int i = 0; i < 48; ++i)
 			g[ph - 1][i] = (i < 24) ? tab[24 * ph + i] : tab[24 * (4 - ph) + (47 - i)];
-	if (mtr_fused_upload_taps (&g[0][0]) || mtr_fused2_upload_taps (&g[0][0])) return fail (MTR_ERR_HIP, "hipMemcpyToSymbol c_fir");
+	if (mtr_fused2_upload_taps (&g[0][0])) return fail (MTR_ERR_HIP, "hipMemcpyToSymbol c_fir");
 	if (e->fir_g.reserve (144) || e->prune_cnt.reserve (4)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_g");
 	HIPCHK (hipMemset (e->prune_cnt.p, 0, 16));
 	HIPCHK (hipMemcpy (e->fir_g.p, g, sizeof (g), hipMemcpyHostToDevice));
@@ -218,11 +222,7 @@ static int upload_consts (mtr_engine* e)
 		HIPCHK (hipMemcpy (e->fir_pmq.p, pmq, sizeof (pmq), hipMemcpyHostToDevice));
 	}
 	{
-		// and as A fragments of the matrix-pipe interpolator (layout 5)
-		std::vector<uint16_t> af (MTR_MFMA_A_HALVES);
-		mtr_mfma_build_a (&g[0][0], af.data ());
-		if (e->mfma_a.reserve (af.size ())) return fail (MTR_ERR_NOMEM, "hipMalloc mfma_a");
-		HIPCHK (hipMemcpy (e->mfma_a.p, af.data (), af.size () * sizeof (uint16_t), hipMemcpyHostToDevice));
+		// and as A fragments of the matrix-pipe interpolator
 		std::vector<uint16_t> a16 (MTR_M16_A_HALVES);
 		mtr_m16_build_a (&g[0][0], a16.data ());
 		if (e->m16_a.reserve (a16.size ())) return fail (MTR_ERR_NOMEM, "hipMalloc m16_a");
@@ -295,7 +295,10 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 		return fail (MTR_ERR_UNSUPPORTED, "EBU / TRUEPEAK need stereo frames (the reference's EBUr128 plugin is stereo only)");
 	if ((cfg->meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && cfg->n_channels != 1)
 		return fail (MTR_ERR_UNSUPPORTED, "BITSTATS / SIGDIST take mono streams (the reference's bitmeter / SigDistHist are mono plugins)");
-	if (cfg->tune_run != 0 && cfg->tune_run != 13 && cfg->tune_run != 19 && cfg->tune_run != 38 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 13, 19, 38 or 39");
+	if (cfg->tune_run != 0 && cfg->tune_run != 19 && cfg->tune_run != 38 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 19, 38 or 39");
+	if (cfg->tune_layout != 0 && cfg->tune_layout != 3 && cfg->tune_layout != 4 && cfg->tune_layout != 6 && cfg->tune_layout != 7)
+		return fail (MTR_ERR_ARG, "tune_layout must be 0, 3, 4, 6 or 7 (layouts 1, 2 and 5 of earlier versions are gone)");
+	if (cfg->tune_fir > 1) return fail (MTR_ERR_ARG, "tune_fir must be 0 or 1");
 
 	int ndev = 0;
 	if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0)
@@ -306,24 +309,28 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	mtr_engine* e = new (std::nothrow) mtr_engine ();
 	if (!e) return fail (MTR_ERR_NOMEM, "new mtr_engine");
 	e->cfg = *cfg;
-	// layout 2 (wave-specialised workgroups, 39-frame lane runs) is the default; layout 1 is the
-	// first design (one wave per stream segment), kept for comparison and for 13-frame runs
-	// (auto = 3: roles rotate over the four waves; measured 1.7 % faster than fixed roles, profiles/r01d)
-	// layout 4 = k_kw, the K-weighting-only kernel (mtr_kw.hip): the default when no true peak is asked for
+	// layout 4 = k_kw, the K-weighting-only kernel (mtr_kw.hip): the default when no true peak is asked for;
+	// layout 6 = k_kwtp16 (mtr_fused4.hip): wherever a true peak is asked for — the interpolator on the matrix pipe at f32
+	//            grade, one wave per (stream, time segment);
+	// layout 7 (the default with a true peak) = layout 6 plus k_seg (mtr_seg.hip, lane = time segment) for every call that
+	//            fits it: a big batch that starts on a fragment boundary (seg_plan below);
+	// layout 3 = the exact-f32 VALU interpolator (mtr_fused2.hip), kept as the bit-for-bit cross-check of the matrix-pipe paths.
 	const bool kw_only = (cfg->meters & MTR_METER_EBU) && !(cfg->meters & MTR_METER_TRUEPEAK);
-	// layout 6 = k_kwtp16 (mtr_fused4.hip): wherever a true peak is asked for — the interpolator on the matrix pipe at f32 grade
 	const bool has_tp = cfg->meters & MTR_METER_TRUEPEAK;
-	e->layout = cfg->tune_layout ? (int) cfg->tune_layout
-	          : cfg->tune_run == 13 ? 1 : kw_only ? 4 : (has_tp && (cfg->tune_run == 0 || cfg->tune_run == 38)) ? 6 : 3;
+	int lay = cfg->tune_layout ? (int) cfg->tune_layout : kw_only ? 4 : (has_tp && (cfg->tune_run == 0 || cfg->tune_run == 38)) ? 7 : 3;
+	e->seg_ok = lay == 7 && cfg->tune_prune == 0;
+	if (lay == 7) lay = 6;
+	e->layout = lay;
 	e->run = cfg->tune_run ? (int) cfg->tune_run : (e->layout == 6 ? 38 : 39);
-	if (e->layout > 6) { delete e; return fail (MTR_ERR_ARG, "tune_layout must be 0..6"); }
-	if ((e->layout == 6) != (e->run == 38)) { delete e; return fail (MTR_ERR_ARG, "layout 6 runs 38-frame lane runs, and only layout 6 does"); }
-	if (e->layout == 6 && !(cfg->meters & MTR_METER_TRUEPEAK)) { delete e; return fail (MTR_ERR_ARG, "layout 6 is a true-peak kernel: needs TRUEPEAK"); }
-	if (e->layout == 5 && (!(cfg->meters & MTR_METER_TRUEPEAK) || e->run == 13)) { delete e; return fail (MTR_ERR_ARG, "layout 5 is the MFMA true-peak kernel: needs TRUEPEAK and tune_run 19 or 39"); }
+	if ((e->layout == 6) != (e->run == 38)) { delete e; return fail (MTR_ERR_ARG, "layouts 6 and 7 run 38-frame lane runs, and only they do"); }
+	if (e->layout == 6 && !has_tp) { delete e; return fail (MTR_ERR_ARG, "layouts 6 and 7 are true-peak kernels: need TRUEPEAK"); }
 	if (e->layout == 4 && !kw_only) { delete e; return fail (MTR_ERR_ARG, "layout 4 is the EBU-only kernel"); }
-	if ((e->layout == 2 || e->layout == 3) && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layouts 2 and 3 need tune_run 39"); }
-	if (e->layout == 4 && e->run == 13) { delete e; return fail (MTR_ERR_ARG, "layout 4 needs tune_run 19 or 39"); }
-	if (e->layout == 1 && e->run == 19) { delete e; return fail (MTR_ERR_ARG, "tune_run 19 is layouts 4 and 5 only"); }
+	if (e->layout == 3 && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layout 3 needs tune_run 39"); }
+	if (e->layout == 4 && e->run != 39 && e->run != 19) { delete e; return fail (MTR_ERR_ARG, "layout 4 needs tune_run 19 or 39"); }
+	{
+		hipDeviceProp_t pr;
+		if (hipGetDeviceProperties (&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->seg_slots = 4u * (uint32_t) pr.multiProcessorCount;
+	}
 	e->fragm = (uint32_t) ((int) cfg->sample_rate / 20);     // ebu_r128_proc.cc:170
 	e->frcnt = e->fragm;
 	mtr_setup_kweight (cfg->sample_rate, e->kw);
@@ -380,7 +387,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	if (e->own_stream) (void) hipStreamDestroy (e->own_stream);
 	if (e->xs_event) (void) hipEventDestroy (e->xs_event);
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
-	e->fir_g.release (); e->mfma_a.release (); e->m16_a.release ();
+	e->fir_g.release (); e->m16_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
 	e->dr_state.release (); e->dr_hist.release (); e->dr_sum.release (); e->dr_peak.release ();
 	e->km_state.release (); e->km_piece.release (); e->km_max.release ();
@@ -584,11 +591,57 @@ int mtr_engine_spectr_reset_peak (mtr_engine* e)
 	return MTR_OK;
 }
 
-// Tiling plan for a call of n_frames starting with `frcnt` frames left in the open fragment.
-static int build_plan (mtr_engine* e, uint64_t N, hipStream_t st)
+// The lane = time segment kernel's share of a call (mtr_seg.hip, layout 7): `tiles` whole fragments from frame 0, cut into
+// n_segs segments per stream of base (+ 1 for the first rem) tiles; every lane walks n_main of them.
+struct SegPlan {
+	bool     use = false;
+	uint32_t tiles = 0, n_segs = 0, base = 0, rem = 0, n_main = 0, warm_steps = 0;
+};
+
+// Does this call go through k_seg?  It must start on a fragment boundary with 16-frame-aligned fragments and 16-byte
+// aligned streams, and it must be a BATCH: the kernel's unit of parallelism is a lane, so it needs ~64 x the units of
+// k_kwtp16 to fill the chip.  The number of segments per stream is the one that minimises the modelled time — rounds of
+// resident waves x steps per wave, a warm-up step (K-filter only) at 0.3 of a full one — and the call takes this path
+// when that beats the model of k_kwtp16 (1.85 x the work per frame, measured: profiles/r03*, always a full machine).
+static SegPlan seg_plan (const mtr_engine* e, const float* d_audio, uint64_t N, uint64_t stride)
+{
+	SegPlan sp;
+	const bool ebu = e->cfg.meters & MTR_METER_EBU;
+	if (!e->seg_ok || e->layout != 6 || e->cfg.n_channels != 2) return sp;
+	if (e->fragm % MTR_SEG_STEP || e->frcnt != e->fragm) return sp;
+	if ((stride & 1) || (reinterpret_cast<uintptr_t> (d_audio) & 15)) return sp;
+	const uint64_t tiles = N / e->fragm;
+	if (tiles == 0 || tiles > 0x7fffffffull / (e->fragm / MTR_SEG_STEP)) return sp;
+	const uint32_t spt = e->fragm / MTR_SEG_STEP;
+	const uint32_t warm_steps = ebu ? ((uint32_t) std::ceil (MTR_WARM_SEC * e->cfg.sample_rate / (float) MTR_SEG_STEP) + 3) / 4 * 4 : 0;
+	const uint32_t warm_tiles = (warm_steps * MTR_SEG_STEP + e->fragm - 1) / e->fragm;
+	const uint64_t S = e->cfg.n_streams;
+	uint64_t gmax = ebu ? tiles / (warm_tiles + 2) : tiles;
+	if (gmax < 1) gmax = 1;
+	if (e->cfg.tune_segments) gmax = std::min<uint64_t> (gmax, e->cfg.tune_segments);
+	const uint64_t g0 = e->cfg.tune_segments ? gmax : 1;
+	double best = 0; uint64_t bg = 0;
+	for (uint64_t g = g0; g <= gmax && g <= 65536; ++g) {
+		const uint64_t waves = (S * g + 63) / 64, rounds = (waves + e->seg_slots - 1) / e->seg_slots;
+		const uint64_t n_main = tiles / g + (tiles % g ? 1 : 0);
+		const double t = (double) rounds * ((double) n_main * spt + (g > 1 ? 0.3 * warm_steps : 0.0));
+		if (!bg || t < best) { best = t; bg = g; }
+	}
+	const double t6 = 1.85 * (double) S * (double) tiles * spt / (64.0 * e->seg_slots);
+	if (!e->cfg.tune_segments && best > t6) return sp;
+	sp.use = true;
+	sp.tiles = (uint32_t) tiles; sp.n_segs = (uint32_t) bg;
+	sp.base = (uint32_t) (tiles / bg); sp.rem = (uint32_t) (tiles % bg); sp.n_main = sp.base + (sp.rem ? 1 : 0);
+	sp.warm_steps = bg > 1 ? warm_steps : 0;
+	return sp;
+}
+
+// Tiling plan for a call of n_frames starting with `frcnt` frames left in the open fragment.  body_tiles > 0: the call
+// starts on a fragment boundary and its first body_tiles tiles are whole fragments (k_seg's part), whatever their length.
+static int build_plan (mtr_engine* e, uint64_t N, uint32_t body_tiles, hipStream_t st)
 {
 	Plan& pl = e->plan;
-	if (pl.valid && pl.n_frames == N && pl.frcnt_in == e->frcnt) return MTR_OK;
+	if (pl.valid && pl.n_frames == N && pl.frcnt_in == e->frcnt && pl.body_tiles == body_tiles) return MTR_OK;
 	pl.valid = false;
 	const uint32_t LT = 64u * (uint32_t) e->run;
 
@@ -598,7 +651,7 @@ static int build_plan (mtr_engine* e, uint64_t N, hipStream_t st)
 	uint32_t left = e->frcnt;
 	ft.push_back (0);
 	while (pos < N) {
-		const uint32_t piece = (uint32_t) std::min<uint64_t> (std::min<uint64_t> (LT, left), N - pos);
+		const uint32_t piece = ts.size () < body_tiles ? e->fragm : (uint32_t) std::min<uint64_t> (std::min<uint64_t> (LT, left), N - pos);
 		ts.push_back ((uint32_t) pos);
 		pos += piece;
 		left -= piece;
@@ -623,6 +676,7 @@ static int build_plan (mtr_engine* e, uint64_t N, hipStream_t st)
 	}
 	const uint64_t max_segs = std::max<uint64_t> (1, N / std::max<uint64_t> (min_seg_frames, 1));
 	n_segs = (uint32_t) std::min<uint64_t> (n_segs, max_segs);
+	if (body_tiles) n_segs = 1;                                 // k_kwtp16 only finishes such a call: one segment (tail_seg)
 	n_segs = std::max<uint32_t> (1, std::min<uint32_t> (n_segs, n_tiles));
 	std::vector<uint32_t> sg (n_segs + 1);
 	for (uint32_t q = 0; q <= n_segs; ++q) sg[q] = (uint32_t) ((uint64_t) q * n_tiles / n_segs);
@@ -638,25 +692,26 @@ static int build_plan (mtr_engine* e, uint64_t N, hipStream_t st)
 	const int slot = (e->plan_cur + 1) % PLAN_SLOTS;
 	PlanSlot& ps = e->plan_slot[slot];
 	if (ps.pending) { HIPCHK (hipEventSynchronize (ps.done)); ps.pending = false; }
-	const size_t words = ts.size () + sg.size () + ft.size ();
+	const uint32_t tseg[2] = { body_tiles, n_tiles };
+	const size_t words = ts.size () + sg.size () + ft.size () + 2;
 	if (ps.dev.reserve (std::max<size_t> (words, 256)) || ps.pin.reserve (std::max<size_t> (words, 256))) return fail (MTR_ERR_NOMEM, "plan slot");
 	if (!ps.done) HIPCHK (hipEventCreateWithFlags (&ps.done, hipEventDisableTiming));
 	memcpy (ps.pin.p, ts.data (), ts.size () * 4);
 	memcpy (ps.pin.p + ts.size (), sg.data (), sg.size () * 4);
 	memcpy (ps.pin.p + ts.size () + sg.size (), ft.data (), ft.size () * 4);
+	memcpy (ps.pin.p + ts.size () + sg.size () + ft.size (), tseg, 8);
 	HIPCHK (hipMemcpyAsync (ps.dev.p, ps.pin.p, words * 4, hipMemcpyHostToDevice, st));
 	e->plan_cur = slot;
 	e->tile_start = ps.dev.p; e->seg_tile = ps.dev.p + ts.size (); e->frag_tile = ps.dev.p + ts.size () + sg.size ();
+	e->tail_seg = e->frag_tile + ft.size ();
 
 	pl.n_frames = N; pl.frcnt_in = e->frcnt; pl.frcnt_out = left;
-	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail;
+	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail; pl.body_tiles = body_tiles;
 	uint32_t maxlen = n_segs > 1 ? LT : 0;                      // warm-up tiles are full tiles
-	for (uint32_t j = 0; j < n_tiles; ++j) maxlen = std::max (maxlen, ts[j + 1] - ts[j]);
+	for (uint32_t j = body_tiles; j < n_tiles; ++j) maxlen = std::max (maxlen, ts[j + 1] - ts[j]);
 	// + look-ahead frames of the FIR register tile + 4 slots for the carried K-filter state (layout 3)
 	pl.buf_slots = (maxlen + 48 + 13 + 4 + 127) / 128 * 128;
 	pl.kw_slots = (maxlen + 1 + 127) / 128 * 128;               // k_kw: the tile + one frame of alignment slack
-	// k_kwtp: halo + the 64 lane runs (written in full, zeros past the tile) + the 9 words a column reads past its window
-	pl.mfma_words = (MTR_FIR_HALO + std::max (maxlen, LT) + 12 + 3) / 4 * 4;
 	pl.valid = true;
 	return MTR_OK;
 }
@@ -705,7 +760,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (tm) { hipEvent_t v = next_event (e, ev0); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 	if (ebu || tp) {
-		int rc = build_plan (e, n_frames, st);
+		const SegPlan sp = seg_plan (e, d_audio, n_frames, stride);
+		int rc = build_plan (e, n_frames, sp.use ? sp.tiles : 0, st);
 		if (rc) return rc;
 		const Plan& pl = e->plan;
 		mtr_fused_args fa;
@@ -720,16 +776,35 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.gain_l = 1.0f; fa.gain_r = 1.0f;                  // _chan_gain[0..1], ebu_r128_proc.cc:29
 		fa.n_frames = n_frames;
 		fa.buf_slots = e->layout >= 4 ? pl.kw_slots : pl.buf_slots;
-		fa.mfma_a = e->layout == 6 ? e->m16_a.p : e->mfma_a.p; fa.mfma_words = pl.mfma_words;
+		fa.mfma_a = e->m16_a.p;
 		fa.fir_form = e->cfg.tune_fir;
 		fa.rotate = e->layout == 3;
 		fa.prune = e->cfg.tune_prune > 2 ? 2 : (int) e->cfg.tune_prune;
 		fa.prune_stats = e->prune_cnt.p;
-		const int lrc = e->layout == 6 ? mtr_launch_kwtp16 (e->run, ebu, fa, S * pl.n_segs, st)
-		              : e->layout == 5 ? mtr_launch_kwtp (e->run, ebu, fa, S * pl.n_segs, st)
-		              : e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
-		              : e->layout >= 2 ? mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st)
-		                               : mtr_launch_fused (e->run, ebu, tp, fa, S * pl.n_segs, st);
+		int lrc = 0;
+		if (sp.use) {
+			// the batch path: whole fragments through k_seg, what is left of the call (less than a fragment) through
+			// k_kwtp16 behind it, as ONE segment that picks the K-filter state up where k_seg's last segment left it
+			mtr_seg_args sa;
+			sa.audio = d_audio; sa.stride = stride; sa.hist = fa.hist; sa.state = e->state.p; sa.tile_power = e->tile_power.p;
+			sa.mfma_a = e->m16_a.p;
+			sa.n_streams = S; sa.n_segs = sp.n_segs; sa.n_tiles = pl.n_tiles; sa.tile_frames = e->fragm;
+			sa.seg_base = sp.base; sa.seg_rem = sp.rem; sa.n_main = sp.n_main; sa.warm_steps = sp.warm_steps;
+			sa.p0_end = (int64_t) n_frames - 24;
+			sa.a0 = fa.a0; sa.a1 = fa.a1; sa.a2 = fa.a2; sa.b1 = fa.b1; sa.b2 = fa.b2; sa.c3 = fa.c3; sa.c4 = fa.c4;
+			sa.gain_l = fa.gain_l; sa.gain_r = fa.gain_r;
+			const uint64_t units = (uint64_t) S * sp.n_segs;
+			lrc = mtr_launch_seg (ebu, sa, (uint32_t) ((units + 63) / 64), st);
+			if (!lrc && pl.n_tiles > sp.tiles) {
+				fa.seg_tile = e->tail_seg; fa.n_segs = 1;
+				lrc = mtr_launch_kwtp16 (e->run, ebu, fa, S, st);
+			}
+			e->seg_calls += 1; e->seg_frames += (uint64_t) sp.tiles * e->fragm;
+		} else {
+			lrc = e->layout == 6 ? mtr_launch_kwtp16 (e->run, ebu, fa, S * pl.n_segs, st)
+			    : e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
+			                     : mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st);
+		}
 		if (lrc) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());
 		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }
 
@@ -838,19 +913,21 @@ int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_fra
 	if (stride < n_frames) return fail (MTR_ERR_ARG, "stream_stride_frames < n_frames");
 	HIPCHK (hipSetDevice (e->cfg.device));
 	const size_t C = e->cfg.n_channels;
-	const size_t total = (size_t) e->cfg.n_streams * n_frames * C;
+	// (streams start on 16 bytes in the staging buffer: an even stride, so that every layout can take the call)
+	const uint64_t dstride = (n_frames + 1) & ~(uint64_t) 1;
+	const size_t total = (size_t) e->cfg.n_streams * dstride * C;
 	hipStream_t st;
 	int rc = host_stream (e, &st);
 	if (rc) return rc;
 	// the staging buffer may still be read by the previous call (on whatever stream that ran)
 	HIPCHK (hipStreamSynchronize (e->last_stream));
 	if (e->stage.reserve (total)) return fail (MTR_ERR_NOMEM, "hipMalloc staging buffer");
-	HIPCHK (hipMemcpy2DAsync (e->stage.p, n_frames * C * sizeof (float), h_audio, stride * C * sizeof (float),
+	HIPCHK (hipMemcpy2DAsync (e->stage.p, dstride * C * sizeof (float), h_audio, stride * C * sizeof (float),
 	                          n_frames * C * sizeof (float), e->cfg.n_streams, hipMemcpyHostToDevice, st));
 	// The source is pageable caller memory and the copy is truly asynchronous: the caller may free
 	// or reuse it as soon as we return, so wait for the copy (not for the kernels) here.
 	HIPCHK (hipStreamSynchronize (st));
-	return mtr_engine_process_device (e, e->stage.p, n_frames, n_frames, st);
+	return mtr_engine_process_device (e, e->stage.p, n_frames, dstride, st);
 }
 
 // One LV2 block: interleave into page-locked memory, one H2D copy, the kernels, one D2H copy of the stream's state
@@ -1088,7 +1165,15 @@ int mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max
 	return MTR_OK;
 }
 
-int mtr_engine_layout (const mtr_engine* e) { return e ? e->layout : MTR_ERR_ARG; }
+int mtr_engine_layout (const mtr_engine* e) { return e ? (e->seg_ok ? 7 : e->layout) : MTR_ERR_ARG; }
+
+int mtr_engine_seg_stats (mtr_engine* e, uint64_t* calls, uint64_t* frames)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	if (calls) *calls = e->seg_calls;
+	if (frames) *frames = e->seg_frames;
+	return MTR_OK;
+}
 
 static int drain_prune_counters (mtr_engine* e)
 {

@@ -20,8 +20,10 @@
 //   5. the next tile's global loads are issued, straight into the run registers (dead from here on);
 //   6. ceil(len / 256) blocks x 2 channels x 18 MFMAs under which those loads land, |max| of the twelve
 //      accumulators, last block masked.
-// Two waves per SIMD.  REGPF = false (tune_fir = 3) is the first form: the f32 tile staged through LDS by LDS-DMA
-// behind the halo, read back transposed, the words written in place over it, the next DMA issued after the products.
+// Two waves per SIMD.  (The first form — the f32 tile staged through LDS by LDS-DMA, read back transposed — was 2-3 %
+// slower on every shape measured and left the library in round 3; so did layouts 1, 2 and 5.)
+// Big batches that start on a fragment boundary take the lane = time segment kernel instead (mtr_seg.hip, layout 7);
+// this kernel serves every other call, and finishes those (the part of the call behind the last whole fragment).
 #include <hip/hip_runtime.h>
 
 #include <utility>
@@ -60,7 +62,7 @@ __device__ __forceinline__ void pow2_scale (uint32_t e_, float& scale, float& un
 	unscale = __uint_as_float ((uint32_t) (239 - se) << 23);      // 2^-(se - 127) * 2^-15
 }
 
-template <int K, bool EBU, bool REGPF>
+template <int K, bool EBU>
 __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 {
 	static_assert ((K & 1) == 0, "even runs: sample pairs never straddle two lanes");
@@ -72,7 +74,6 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 	uint32_t* const HR = HL + WN;
 	uint32_t* const LL = HL + 2 * WN;
 	uint32_t* const LR = HL + 3 * WN;
-	v2f* const buf = reinterpret_cast<v2f*> (smem);                    // f32 view: slot off + i <-> position i (frame t0 - 48 + i)
 	const int lane = threadIdx.x;
 
 	const uint32_t unit = blockIdx.x;
@@ -96,34 +97,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		if (jj < 0) { t0 = seg_start + (int64_t) jj * LT; len = LT; }
 		else        { t0 = a.tile_start[jt0 + jj]; len = (int) (a.tile_start[jt0 + jj + 1] - (uint32_t) t0); }
 	};
-	// Frames [t0 - off, t0 + len) -> slots [HALO, HALO + off + len), off = t0 & 1: the DMA source stays 16-byte aligned.
-	// Then zeros behind the tile up to the end of the last lane's run: nothing below needs a per-frame length test.
-	auto stage = [&] (int jj) {
-		int64_t t0; int len;
-		tile_of (jj, t0, len);
-		const int off = (int) (t0 & 1);
-		const int nslot = len + off;
-		const bool tail_odd = (t0 + len == (int64_t) a.n_frames) && (a.n_frames & 1);
-		if (src_even && !tail_odd) {
-			// whole 1 KiB pieces first (128 slots each, every lane takes part), four per address update, then the
-			// tile's last, partial piece under a lane mask
-			const v2f* p = src + (t0 - off) + 2 * lane;
-			v2f* d = buf + HALO;
-#define MTR_DMA(k) __builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void*) (p + 128 * (k)), \
-                                                     (__attribute__ ((address_space (3))) void*) (d + 128 * (k)), 16, 0, 0)
-			int i = 0;
-			for (; i + 512 <= nslot; i += 512, p += 512, d += 512) { MTR_DMA (0); MTR_DMA (1); MTR_DMA (2); MTR_DMA (3); }
-			for (; i + 128 <= nslot; i += 128, p += 128, d += 128) MTR_DMA (0);
-			if (i + 2 * lane < nslot) MTR_DMA (0);
-#undef MTR_DMA
-		} else {
-			for (int i = lane; i < nslot; i += 64) buf[HALO + i] = src[t0 - off + i];
-		}
-		// (an odd nslot leaves slot HALO + nslot to the last 16-byte DMA piece: that one is cleared once the tile has landed)
-		for (int i = HALO + ((nslot + 1) & ~1) + lane; i < HALO + off + LT; i += 64) buf[i] = v2f{0.f, 0.f};
-	};
-
-	// REGPF: the next tile goes straight into the run registers — which are dead during the products — with per-lane
+	// The next tile goes straight into the run registers — which are dead during the products — with per-lane
 	// global loads issued BEFORE the MFMA phase: lane l reads its own 304 contiguous bytes (19 x 16 bytes; the 64 lanes
 	// of one instruction touch 64 cache lines, each of which the following seven instructions hit again in the L1),
 	// lanes 0..23 the two halo frames in front of the tile.  No f32 image in LDS, no DMA issue behind the products, no
@@ -171,19 +145,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 	// warm-up tiles, whose own halo is never multiplied.  Lane i < 24 holds positions 2 i and 2 i + 1.
 	v2f h0 = v2f{0.f, 0.f}, h1 = v2f{0.f, 0.f};
 	v2f x[K];
-	if (REGPF) {
-		fetch (-nwarm, x, h0, h1);
-	} else {
-		if (q == 0 && lane < HALO / 2) {
-			if (lane > 0) h0 = hst[2 * lane - 1];
-			h1 = hst[2 * lane];
-		}
-		int64_t t0; int len;
-		tile_of (-nwarm, t0, len);
-		const int off = (int) (t0 & 1);
-		if (lane < HALO / 2) { buf[off + 2 * lane] = h0; buf[off + 2 * lane + 1] = h1; }
-		stage (-nwarm);
-	}
+	fetch (-nwarm, x, h0, h1);
 	const int wrun = HALO / 2 + (K / 2) * lane;                        // first word of this lane's run in each array
 	const int col8 = 8 * (lane & 15), kg4 = 4 * (lane >> 4);
 
@@ -193,10 +155,9 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 	for (int jj = -nwarm; jj < ntile; ++jj) {
 		int64_t t0; int len;
 		tile_of (jj, t0, len);
-		const int off = (int) (t0 & 1);
 
 		PROF_NOW (c0_);
-		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed (in LDS, or in the run registers)
+		asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");      // this tile has landed in the run registers
 		PROF_NOW (c1_); PROF_ADD (0, c1_ - c0_);
 		// the per-lane matrices of the scan's row-broadcast steps: 24 registers, fetched per tile (L1 / L2 hits that
 		// land under the split) rather than held across the products
@@ -205,22 +166,6 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 
 		// this tile's halo (positions 0..47) is in h0 / h1
 		const v2f ph0 = h0, ph1 = h1;
-		if (!REGPF) {
-			__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
-			if (((len + off) & 1) && lane == 0) buf[HALO + off + len] = v2f{0.f, 0.f};
-			if (off == 0) {
-				const float4* const p4 = reinterpret_cast<const float4*> (buf + HALO + K * lane);
-#pragma unroll
-				for (int i = 0; i < K / 2; ++i) { const float4 v = p4[i]; x[2 * i] = v2f{v.x, v.y}; x[2 * i + 1] = v2f{v.z, v.w}; }
-			} else {
-				const v2f* const xr = buf + HALO + 1 + K * lane;
-#pragma unroll
-				for (int n = 0; n < K; ++n) x[n] = xr[n];
-			}
-			// the next tile's halo = the last 48 positions of halo ++ tile
-			if (lane < HALO / 2) { h0 = buf[off + len + 2 * lane]; h1 = buf[off + len + 2 * lane + 1]; }
-			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");    // every read has returned: the f32 image is dead
-		}
 		PROF_NOW (c2_); PROF_ADD (1, c2_ - c1_);
 
 		// per-lane max |x| per channel
@@ -231,7 +176,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		if (lane < HALO / 2) { hl = fmaxf (fabsf (ph0.x), fabsf (ph1.x)); hr = fmaxf (fabsf (ph0.y), fabsf (ph1.y)); }
 		// The scales need only the exponents of the two window maxima: both ride through ONE wave reduction as a pair
 		// of 16-bit fields (v_pk_max_u16); NaNs have lost every fmaxf above, an Inf gives exponent 255.
-		const bool inside = !REGPF || K * lane < len;                 // REGPF: lanes past the tile hold the next tile's frames
+		const bool inside = K * lane < len;                           // lanes past the tile hold the next tile's frames
 		const uint32_t epair = (__float_as_uint (fmaxf (inside ? ml : 0.f, hl)) >> 23) | ((__float_as_uint (fmaxf (inside ? mr : 0.f, hr)) >> 23) << 16);
 		const uint32_t emax = mtrw::max63_u16x2 (epair);
 
@@ -240,7 +185,7 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		// kept per lane and reduced once, at the end of the segment.
 		if (jj >= 0) {
 			float il = ml, ir = mr;
-			if (t0 + (REGPF ? LT : len) > id_end) {
+			if (t0 + LT > id_end) {
 				il = 0.f; ir = 0.f;
 				const int64_t lim = id_end - t0 - (int64_t) K * lane;          // frames of this lane's run inside the range
 #pragma unroll
@@ -341,9 +286,9 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		}
 
 		PROF_NOW (c5_); PROF_ADD (4, c5_ - c4_);
-		// REGPF: the run registers are dead from here on: the next tile's loads go out now and land under the products
+		// the run registers are dead from here on: the next tile's loads go out now and land under the products
 		v2f xn[K], g0 = v2f{0.f, 0.f}, g1 = v2f{0.f, 0.f};
-		if (REGPF && jj + 1 < ntile) fetch (jj + 1, xn, g0, g1);
+		if (jj + 1 < ntile) fetch (jj + 1, xn, g0, g1);
 		// The interpolator: 256 output frames x 3 phases per block and channel.  Operands ping-pong between the channels:
 		// the right channel's fragments land under the left channel's 18 products and the next block's left fragments
 		// under the right channel's; each channel's |max| rides between the other channel's MFMAs (two VALU
@@ -478,20 +423,9 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 		}
 		PROF_NOW (c6_); PROF_ADD (5, c6_ - c5_);
 
-		if (REGPF) {
 #pragma unroll
-			for (int n = 0; n < K; ++n) x[n] = xn[n];
-			h0 = g0; h1 = g1;
-		}
-		// (LDS-staged form) the next tile: halo as f32 in front of it, DMA over the spent words
-		if (!REGPF && jj + 1 < ntile) {
-			asm volatile ("s_waitcnt lgkmcnt(0)" ::: "memory");
-			int64_t t1; int len1;
-			tile_of (jj + 1, t1, len1);
-			const int off1 = (int) (t1 & 1);
-			if (lane < HALO / 2) { buf[off1 + 2 * lane] = h0; buf[off1 + 2 * lane + 1] = h1; }
-			stage (jj + 1);
-		}
+		for (int n = 0; n < K; ++n) x[n] = xn[n];
+		h0 = g0; h1 = g1;
 		PROF_NOW (c7_); PROF_ADD (6, c7_ - c6_); PROF_ADD (7, c7_ - c0_); PROF_ADD (8, 1);
 	}
 #ifdef MTR_F4_PROF
@@ -518,17 +452,9 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 template <int K>
 int launch_kwtp16 (bool ebu, const mtr_fused_args& a, uint32_t n_units, hipStream_t st)
 {
-	const size_t words = (size_t) 4 * ((HALO + 64 * K) / 2) * sizeof (uint32_t);
-	const size_t tile = (size_t) (HALO + 1 + 64 * K) * sizeof (v2f);
-	const size_t lds = ((words > tile ? words : tile) + 15) & ~(size_t) 15;
-	// tune_fir = 3: the LDS-staged form (LDS-DMA of the f32 tile, transposing read), kept for comparison
-	if (a.fir_form == 3) {
-		if (ebu) hipLaunchKernelGGL ((k_kwtp16<K, true, false>), dim3 (n_units), dim3 (64), lds, st, a);
-		else     hipLaunchKernelGGL ((k_kwtp16<K, false, false>), dim3 (n_units), dim3 (64), lds, st, a);
-	} else {
-		if (ebu) hipLaunchKernelGGL ((k_kwtp16<K, true, true>), dim3 (n_units), dim3 (64), lds, st, a);
-		else     hipLaunchKernelGGL ((k_kwtp16<K, false, true>), dim3 (n_units), dim3 (64), lds, st, a);
-	}
+	const size_t lds = ((size_t) 4 * ((HALO + 64 * K) / 2) * sizeof (uint32_t) + 15) & ~(size_t) 15;
+	if (ebu) hipLaunchKernelGGL ((k_kwtp16<K, true>), dim3 (n_units), dim3 (64), lds, st, a);
+	else     hipLaunchKernelGGL ((k_kwtp16<K, false>), dim3 (n_units), dim3 (64), lds, st, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
@@ -540,6 +466,30 @@ extern "C" int mtr_debug_f4_prof (unsigned long long* out)
 	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_f4_prof), 12 * sizeof (unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// New 47-frame history = the last 47 frames of (old history ++ this call's audio): what Resampler::process keeps in its
+// window between calls (zita-resampler/resampler.cc:229-262).
+__global__ void k_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
+                           float* hist_out, uint32_t n_streams)
+{
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_streams * MTR_FIR_HALO) return;
+	const uint32_t s = g / MTR_FIR_HALO, i = g % MTR_FIR_HALO;
+	const int64_t f = (int64_t) n_frames - MTR_FIR_HALO + i;   // frame index in this call, may be < 0
+	const v2f* src = reinterpret_cast<const v2f*> (audio) + (size_t) s * stride;
+	const v2f* hin = reinterpret_cast<const v2f*> (hist_in) + (size_t) s * MTR_FIR_HALO;
+	v2f* hout = reinterpret_cast<v2f*> (hist_out) + (size_t) s * MTR_FIR_HALO;
+	hout[i] = (f >= 0) ? src[f] : hin[MTR_FIR_HALO + f];
+}
+
+int mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
+                        float* hist_out, uint32_t n_streams, void* stream)
+{
+	const uint32_t n = n_streams * MTR_FIR_HALO;
+	hipLaunchKernelGGL (k_history, dim3 ((n + 255) / 256), dim3 (256), 0, (hipStream_t) stream,
+	                    audio, stride, n_frames, hist_in, hist_out, n_streams);
+	return hipGetLastError () == hipSuccess ? 0 : -1;
+}
 
 int mtr_launch_kwtp16 (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream)
 {

@@ -46,12 +46,30 @@ struct mtr_fused_args {
 	uint32_t        rotate;       /* wave-specialised kernel: rotate the loader / K-filter role over the four waves */
 	uint32_t        prune;        /* exact peak pruning: skip the interpolator where L1 * max|x| cannot beat the running peak */
 	uint32_t*       prune_stats;  /* [4] tile passes considered / skipped, channel-blocks screened / completed (device counters), may be NULL */
-	const uint16_t* mfma_a;       /* layout 5: A fragments of the MFMA interpolator, [7][64][8] halves (mtr_mfma_fir.h);
-	                               * layout 6: [12][64][8] hi / lo fragments (mtr_mfma16_fir.h) */
-	uint32_t        mfma_words;   /* layout 5: LDS words per channel of the {hi, lo} sample arrays (multiple of 4) */
+	const uint16_t* mfma_a;       /* layout 6: [12][64][8] hi / lo A fragments of the matrix-pipe interpolator (mtr_mfma16_fir.h) */
 	float           a0, a1, a2, b1, b2, c3, c4;
 	float           gain_l, gain_r;
 };
+
+/* Arguments of the lane = time segment kernel (mtr_seg.hip, layout 7).  The launch covers the tiles [0, n_body) of a call
+ * that starts on a fragment boundary; every tile is tile_frames long (a multiple of MTR_SEG_STEP).  Segment q of a stream
+ * answers for seg_base + (q < seg_rem) consecutive tiles, and every lane processes n_main = seg_base + (seg_rem > 0) of
+ * them, starting one tile early where its own segment is the shorter kind. */
+#define MTR_SEG_STEP 16            /* frames per lane and step: one column of the block-Toeplitz product */
+typedef struct mtr_seg_args {
+	const float*    audio;        /* [S][stride][2], 16-byte aligned, stride even */
+	uint64_t        stride;       /* frames */
+	const float*    hist;         /* [S][47][2]: the 47 frames before frame 0 of this call */
+	mtr_stream_state* state;      /* [S] */
+	float*          tile_power;   /* [S][n_tiles] */
+	const uint16_t* mfma_a;       /* [12][64][8] hi / lo A fragments (mtr_mfma16_fir.h) */
+	uint32_t        n_streams, n_segs, n_tiles, tile_frames;
+	uint32_t        seg_base, seg_rem, n_main;
+	uint32_t        warm_steps;   /* K-filter warm-up in front of a segment that does not start the call: steps of 16 frames, multiple of 4 */
+	int64_t         p0_end;       /* phase 0 (|x[n - 24]|) of this call covers the frames below n_frames - 24 */
+	float           a0, a1, a2, b1, b2, c3, c4;
+	float           gain_l, gain_r;
+} mtr_seg_args;
 
 struct mtr_gate_args {
 	mtr_stream_state* state;      /* [S] */
@@ -158,17 +176,16 @@ void mtr_setup_hist_loudness (const int32_t* hist_M, const int32_t* hist_S, floa
 }
 
 /* kernel launchers (one per HIP TU) */
-int  mtr_launch_fused (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_fused2 (int run, bool ebu, bool tp, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kw (int run, const mtr_fused_args& a, uint32_t n_units, void* stream);
-int  mtr_launch_kwtp (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
 int  mtr_launch_kwtp16 (int run, bool ebu, const mtr_fused_args& a, uint32_t n_units, void* stream);
+int  mtr_launch_seg (bool ebu, const mtr_seg_args& a, uint32_t n_waves, void* stream);
+size_t mtr_seg_lds_bytes (void);
 int  mtr_launch_dr14 (const mtr_dr14_args& a, void* stream);
 int  mtr_launch_kmeter (const mtr_kmeter_args& a, void* stream);
 void mtr_kmeter_powers (float omega, double* pw1 /* [3] */);
 uint32_t mtr_kmeter_pieces (uint64_t n_groups);
 int  mtr_fused2_upload_taps (const float* g144);
-int  mtr_fused_upload_taps (const float* g144);    /* [3][48] full 48-tap kernels of phases 1..3 */
 int  mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
                          float* hist_out, uint32_t n_streams, void* stream);
 int  mtr_launch_gate (const mtr_gate_args& a, void* stream);

@@ -87,14 +87,22 @@ struct AFrag {
 
 // Two consecutive samples of one channel, already scaled: hi = round-to-nearest f16 pair, lo = the exact f32
 // remainders rounded to f16 (v_fma_mix: f16 source, f32 addend, f16 result — one instruction per half).
-__device__ __forceinline__ void split_pair (float x0, float x1, uint32_t& hi, uint32_t& lo)
+__device__ __forceinline__ uint32_t hi_pair (float x0, float x1)
 {
-	const h2 h = __builtin_convertvector (v2f_{x0, x1}, h2);           // v_cvt_pk_f16_f32
-	uint32_t hw = __builtin_bit_cast (uint32_t, h), lw;
+	return __builtin_bit_cast (uint32_t, __builtin_convertvector (v2f_{x0, x1}, h2));           // v_cvt_pk_f16_f32
+}
+__device__ __forceinline__ uint32_t lo_pair (uint32_t hw, float x0, float x1)
+{
+	uint32_t lw;
 	asm ("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
 	     "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
 	     : "=&v"(lw) : "v"(hw), "v"(x0), "v"(x1));
-	hi = hw; lo = lw;
+	return lw;
+}
+__device__ __forceinline__ void split_pair (float x0, float x1, uint32_t& hi, uint32_t& lo)
+{
+	hi = hi_pair (x0, x1);
+	lo = lo_pair (hi, x0, x1);
 }
 
 // the four operand fragments of one channel for one 256-frame block: hi / lo x window steps 0, 1
@@ -127,6 +135,18 @@ __device__ __forceinline__ void block (const AFrag& A, const BFrag& B, f4 (&y)[3
 	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 0) * 2 + 1], B.h0, y[p]);
 #pragma unroll
 	for (int p = 0; p < 3; ++p) M16_MFMA (A.a[(p * 2 + 1) * 2 + 1], B.h1, y[p]);
+}
+
+// MFMA number I (0..17) of block (), for a caller that places other work between the products by hand (mtr_seg.hip);
+// I < 3 start from a zero accumulator.
+template <int I>
+__device__ __forceinline__ void block_mfma (const AFrag& A, const BFrag& B, f4 (&y)[3])
+{
+	constexpr int g = I / 3, p = I % 3;
+	constexpr int ai = (p * 2 + (g & 1)) * 2 + (g >= 4 ? 1 : 0);
+	const uint4& b = g == 0 ? B.h0 : g == 1 ? B.h1 : g == 2 ? B.l0 : g == 3 ? B.l1 : g == 4 ? B.h0 : B.h1;
+	const f4 c = I < 3 ? f4{0.f, 0.f, 0.f, 0.f} : y[p];
+	y[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16 (A.a[ai], __builtin_bit_cast (h8, b), c, 0, 0, 0);
 }
 
 // The same products in two instalments, for the refinement form of exact pruning (tune_prune = 2): block_first is

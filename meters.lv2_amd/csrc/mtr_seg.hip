@@ -1,0 +1,465 @@
+// mtr_seg.hip — K-weighting + true peak with LANE = TIME SEGMENT (gfx950), layout 7: the batch path.
+//
+// Replaces, for a whole batch, Ebu_r128_proc::detect_process (ebumeter/ebu_r128_proc.cc:302-337) and
+// Resampler::process + TruePeakdsp::process_max (zita-resampler/resampler.cc:211-235, jmeters/truepeakdsp.cc:101-124),
+// like k_kwtp16 (mtr_fused4.hip), whose arithmetic it shares: the K-weighting step is the reference's recurrence in f32,
+// the interpolator runs on v_mfma_f32_16x16x32_f16 with samples and taps split into two f16 halves and three of the
+// four partial products kept (mtr_mfma16_fir.h).
+//
+// What is different is the decomposition.  k_kwtp16 gives a wave ONE stream and its 64 lanes consecutive 38-frame runs
+// of one 50 ms tile: the serial K-filter then needs an end-state pass, a DPP scan and a masked second pass (22 packed
+// instructions per frame instead of the recurrence's 11), every tile has serial phases (scale reduction, split, pass 1,
+// scan, pass 2, products), and its two waves per SIMD take turns (tools/f4_census.py: 1353 VALU + 342 MFMA + 361 SALU per
+// tile).  Here a lane owns a whole TIME SEGMENT of a stream (the 64 lanes of a wave = 64 (stream, segment) units) and
+// walks it 16 frames per step:
+//   * the K-filter is the plain recurrence, 11 packed instructions per frame, state in registers; a segment that does
+//     not start the call is warmed up over the 0.2 s in front of it (slowest pole 0.99502 per sample: 1e-21 — what
+//     k_kwtp16's own time segments do), segment 0 starts from the carried state;
+//   * the 16 new frames of a lane are ONE column of the block-Toeplitz product: rows = the 16 outputs, window = the
+//     lane's last 64 samples, which sit in a four-slot ring in LDS (f16 hi / lo words, 144 bytes per column and
+//     array: conflict-free ds_read_b128 / ds_write_b128).  One step = 64 columns = 4 blocks x 2 channels x 18 MFMAs;
+//   * the scale of a column is its lane's own: a power of two that puts the segment's running maximum into
+//     [2^3, 2^15) — it only ever shrinks, and when it must (a sample 2^12 above what the scale was made for) the lane's
+//     ring words are rescaled in place (exact: a power of two) and the peaks so far leave the scaled domain.  An Inf
+//     or NaN sample poisons only the columns it reaches;
+//   * no tile phases: every step is the same code, and the products of step j - 1 run UNDER the scalar and packed work
+//     of step j in one instruction stream (one wave per SIMD, all the registers, 38 KB of LDS) — the MFMA shadows
+//     carry the split, the maxima and half of the recurrence (tools/coissue.hip: one packed or two scalar VALU
+//     instructions per 16x16x32 MFMA are free);
+//   * loads: lane l reads its own 128 bytes per step (8 x global_load_dwordx4, one cache line), three steps ahead.
+//
+// The launch covers whole 50 ms tiles [0, n_main tiles per lane) of a call that starts on a fragment boundary; what is
+// left of the call (less than one tile, or a stream that ends within 48 frames of its stride) goes to k_kwtp16 in the
+// same stream order (mtr_engine.hip).  Σ y² per tile leaves through tile_power exactly as from k_kwtp16, so k_gate does
+// not know which kernel ran.
+#include <hip/hip_runtime.h>
+
+#include "mtr_internal.h"
+#include "mtr_mfma16_fir.h"
+#include "mtr_wave.h"
+
+namespace {
+
+constexpr int R     = MTR_SEG_STEP;          // frames per lane and step = one MFMA column
+constexpr int COLB  = 144;                   // bytes per column and array: 4 ring slots x 32 + 16 of padding (bank spread)
+constexpr int ARRB  = 64 * COLB;             // one array: HL | HR | LL | LR
+constexpr int BLKB  = 16 * COLB;             // 16 columns = one MFMA block
+constexpr int XCHG  = 4 * ARRB;              // exchange area: float [2 ch][4 blocks][4 kg][16 c]
+constexpr int LDS_BYTES = XCHG + 2048;
+#ifndef MTR_SEG_VPM
+#define MTR_SEG_VPM 1               // VALU instructions scheduled behind every MFMA of a step (tools/coissue.hip: one packed or two scalar are free)
+#endif
+
+typedef unsigned char lds_u8;          // (generic pointers into the dynamic LDS block: the compiler infers the address space)
+
+__device__ __forceinline__ float max3abs (float m, float a, float b) { return fmaxf (fmaxf (m, fabsf (a)), fabsf (b)); }
+__device__ __forceinline__ v2f fma2 (v2f a, v2f b, v2f c) { return __builtin_elementwise_fma (a, b, c); }
+__device__ __forceinline__ v2f scrub (v2f v) { return v2f{isfinite (v.x) ? v.x : 0.f, isfinite (v.y) ? v.y : 0.f}; }
+
+// The scale of one channel of one lane.  A running maximum with exponent field e goes to [2^3, 2^4); the scale stands
+// until a sample reaches 2^15 under it (cap = the bit pattern of that sample: non-negative floats order as uints, an
+// Inf sets cap above every pattern).
+struct Scale {
+	float sc, un;          // scale, 2^-15 / scale
+	uint32_t cap;
+	__device__ __forceinline__ void set (float mx)
+	{
+		const int e = (int) (__float_as_uint (mx) >> 23);
+		const int se = min (238, 257 - e);
+		sc = __uint_as_float ((uint32_t) se << 23);
+		un = __uint_as_float ((uint32_t) (239 - se) << 23);
+		cap = (uint32_t) (269 - se) << 23;
+	}
+};
+
+struct KCoef { v2f a0, a1, a2, b1, b2, c3, c4, eps; };
+struct KState { v2f z1, z2, z3, z4, sj; };
+
+// ebu_r128_proc.cc:321-327 for both channels of a frame; the association of mtr_kw_steps.h's hand-scheduled pair
+__device__ __forceinline__ void kstep (const KCoef& k, KState& s, v2f p)
+{
+	v2f t = p + k.eps;
+	v2f u = k.a1 * s.z1;
+	t = fma2 (-k.b2, s.z2, t);
+	u = fma2 (k.a2, s.z2, u);
+	const v2f x = fma2 (-k.b1, s.z1, t);
+	u = fma2 (-k.c4, s.z4, u);
+	s.z4 = s.z4 + s.z3;
+	u = fma2 (-k.c3, s.z3, u);
+	const v2f y = fma2 (k.a0, x, u);
+	s.z3 = s.z3 + y;
+	s.sj = fma2 (y, y, s.sj);
+	s.z2 = s.z1; s.z1 = x;
+}
+
+// the same step as eleven separate operations, for the hand-placed schedule of the main loop
+struct KTmp { v2f t, u, x, y; };
+template <int N>
+__device__ __forceinline__ void kop (const KCoef& k, KState& s, KTmp& w, v2f p)
+{
+	if constexpr (N == 0) w.t = p + k.eps;
+	else if constexpr (N == 1) w.u = k.a1 * s.z1;
+	else if constexpr (N == 2) w.t = fma2 (-k.b2, s.z2, w.t);
+	else if constexpr (N == 3) w.u = fma2 (k.a2, s.z2, w.u);
+	else if constexpr (N == 4) w.x = fma2 (-k.b1, s.z1, w.t);
+	else if constexpr (N == 5) w.u = fma2 (-k.c4, s.z4, w.u);
+	else if constexpr (N == 6) s.z4 = s.z4 + s.z3;
+	else if constexpr (N == 7) w.u = fma2 (-k.c3, s.z3, w.u);
+	else if constexpr (N == 8) w.y = fma2 (k.a0, w.x, w.u);
+	else if constexpr (N == 9) s.z3 = s.z3 + w.y;
+	else { s.sj = fma2 (w.y, w.y, s.sj); s.z2 = s.z1; s.z1 = w.x; }
+}
+
+template <bool EBU>
+__global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
+{
+	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem_[];
+	lds_u8* const smem = smem_;
+	const int lane = threadIdx.x;
+
+	// ---- which (stream, segment) this lane owns --------------------------------------------------------------------------
+	const uint32_t n_units = a.n_streams * a.n_segs;
+	uint32_t unit = blockIdx.x * 64u + (uint32_t) lane;
+	const bool live = unit < n_units;                               // lanes past the batch shadow the last unit, silently
+	if (!live) unit = n_units - 1;
+	const uint32_t s = unit / a.n_segs, q = unit - s * a.n_segs;
+	const uint32_t fq = q * a.seg_base + min (q, a.seg_rem);          // first tile this lane answers for
+	const uint32_t cq = a.seg_base + (q < a.seg_rem ? 1u : 0u);
+	const uint32_t p0 = fq + cq - a.n_main;                           // first tile it processes (one early where its segment is short)
+	const int64_t F0 = (int64_t) p0 * a.tile_frames;
+	const v2f* const src = reinterpret_cast<const v2f*> (a.audio) + (size_t) s * a.stride;
+	mtr_stream_state* const st = a.state + s;
+	const int n_steps = (int) (a.n_main * (a.tile_frames / R));
+	const int spt = (int) (a.tile_frames / R);
+
+	KCoef kc;
+	kc.a0 = a.a0; kc.a1 = a.a1; kc.a2 = a.a2; kc.b1 = a.b1; kc.b2 = a.b2; kc.c3 = a.c3; kc.c4 = a.c4; kc.eps = 1e-15f;
+	KState ks;
+	ks.z1 = 0; ks.z2 = 0; ks.z3 = 0; ks.z4 = 0; ks.sj = 0;
+	if (EBU && q == 0) {
+		ks.z1 = v2f{st->kz[0], st->kz[1]}; ks.z2 = v2f{st->kz[2], st->kz[3]};
+		ks.z3 = v2f{st->kz[4], st->kz[5]}; ks.z4 = v2f{st->kz[6], st->kz[7]};
+	}
+
+	// ---- the stream: four register buffers of 16 frames, loaded three steps ahead ------------------------------------------
+	const bool warm = EBU && q > 0;
+	const float4* lp = reinterpret_cast<const float4*> (src + F0 - (warm ? (int64_t) a.warm_steps * R : 0));
+	v2f xq[4][R];
+	auto load = [&]<int B> () __attribute__ ((always_inline)) {
+#pragma unroll
+		for (int i = 0; i < R / 2; ++i) { const float4 v = lp[i]; xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w}; }
+	};
+	load.template operator()<0> (); lp += R / 2;
+	load.template operator()<1> (); lp += R / 2;
+	load.template operator()<2> (); lp += R / 2;
+
+	m16::AFrag A;
+	A.load (a.mfma_a, lane);
+
+	// ---- K-filter warm-up of the segments that do not start the call (warm_steps is a multiple of 4) -------------------------
+	if (warm) {
+		for (uint32_t w = 0; w < a.warm_steps; w += 4) {
+#define MTR_WARM(B)                                                              \
+			{                                                                        \
+				_Pragma ("unroll") for (int n = 0; n < R; ++n) kstep (kc, ks, xq[B][n]); \
+				load.template operator()<(B + 3) & 3> (); lp += R / 2;                \
+			}
+			MTR_WARM (0) MTR_WARM (1) MTR_WARM (2) MTR_WARM (3)
+#undef MTR_WARM
+		}
+		ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);
+		ks.sj = 0;
+	}
+
+	// ---- the ring: 48 frames in front of the segment (history of the previous call for segment 0) ---------------------------
+	const int cc = lane & 15, kg = lane >> 4;
+	int RA[4];                                                        // operand read address of window quarter v, this lane
+#pragma unroll
+	for (int v = 0; v < 4; ++v) RA[v] = cc * COLB + (kg & 1) * 16 + ((v + (kg >> 1)) & 3) * 32;
+	const int WA = lane * COLB;                                       // this lane's column
+
+	Scale scl, scr;
+	v2f pk0 = v2f{0.f, 0.f};                                           // phase 0: max |x[n - 24]|, exact
+	v2f pkf = v2f{0.f, 0.f};                                           // interpolated peaks that have left the scaled domain
+	float pm[4][2];                                                   // running |max| of the accumulators, scaled, per block and channel
+#pragma unroll
+	for (int b = 0; b < 4; ++b) { pm[b][0] = 0.f; pm[b][1] = 0.f; }
+
+	auto split_store = [&] (const v2f (&x)[R], int slot) __attribute__ ((always_inline)) {
+		const v2f sc = v2f{scl.sc, scr.sc};
+		uint32_t hl[R / 2], hr[R / 2], ll[R / 2], lr[R / 2];
+#pragma unroll
+		for (int i = 0; i < R / 2; ++i) {
+			const v2f u = x[2 * i] * sc, v = x[2 * i + 1] * sc;
+			m16::split_pair (u.x, v.x, hl[i], ll[i]);
+			m16::split_pair (u.y, v.y, hr[i], lr[i]);
+		}
+		lds_u8* const w = smem + WA + slot * 32;
+		*reinterpret_cast<uint4*> (w)                 = uint4{hl[0], hl[1], hl[2], hl[3]};
+		*reinterpret_cast<uint4*> (w + 16)            = uint4{hl[4], hl[5], hl[6], hl[7]};
+		*reinterpret_cast<uint4*> (w + ARRB)          = uint4{hr[0], hr[1], hr[2], hr[3]};
+		*reinterpret_cast<uint4*> (w + ARRB + 16)     = uint4{hr[4], hr[5], hr[6], hr[7]};
+		*reinterpret_cast<uint4*> (w + 2 * ARRB)      = uint4{ll[0], ll[1], ll[2], ll[3]};
+		*reinterpret_cast<uint4*> (w + 2 * ARRB + 16) = uint4{ll[4], ll[5], ll[6], ll[7]};
+		*reinterpret_cast<uint4*> (w + 3 * ARRB)      = uint4{lr[0], lr[1], lr[2], lr[3]};
+		*reinterpret_cast<uint4*> (w + 3 * ARRB + 16) = uint4{lr[4], lr[5], lr[6], lr[7]};
+	};
+
+	{
+		const v2f* const hst = reinterpret_cast<const v2f*> (a.hist) + (size_t) s * MTR_FIR_HALO;
+		v2f px[3][R];
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+#pragma unroll
+			for (int n = 0; n < R; ++n) {
+				const int64_t f = F0 - 48 + R * k + n;
+				px[k][n] = f >= 0 ? src[f] : (f >= -MTR_FIR_HALO ? hst[f + MTR_FIR_HALO] : v2f{0.f, 0.f});
+			}
+		float ml = 0.f, mr = 0.f;
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+#pragma unroll
+			for (int n = 0; n < R; n += 2) { ml = max3abs (ml, px[k][n].x, px[k][n + 1].x); mr = max3abs (mr, px[k][n].y, px[k][n + 1].y); }
+		scl.set (ml); scr.set (mr);
+		split_store (px[0], 1); split_store (px[1], 2); split_store (px[2], 3);
+		if (F0 == 0) {
+			// phase 0 of this call starts with frames -24 .. -1 (the launch starts the call; the call is longer than 48 frames)
+#pragma unroll
+			for (int n = 8; n < R; ++n) pk0 = v2f{fmaxf (pk0.x, fabsf (px[1][n].x)), fmaxf (pk0.y, fabsf (px[1][n].y))};
+#pragma unroll
+			for (int n = 0; n < R; ++n) pk0 = v2f{fmaxf (pk0.x, fabsf (px[2][n].x)), fmaxf (pk0.y, fabsf (px[2][n].y))};
+		}
+	}
+
+	// ---- pieces of a step ---------------------------------------------------------------------------------------------------
+	// the accumulators' running maxima leave the scaled domain: pm (accumulator layout: lane (c, kg), block b = column
+	// 16 b + c) -> pkf of the lane that owns the column, through the exchange area
+	auto flush_pm = [&] () __attribute__ ((always_inline)) {
+		float* const X = reinterpret_cast<float*> (smem_ + XCHG);
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			X[((0 * 4 + b) * 4 + kg) * 16 + cc] = pm[b][0];
+			X[((1 * 4 + b) * 4 + kg) * 16 + cc] = pm[b][1];
+			pm[b][0] = 0.f; pm[b][1] = 0.f;
+		}
+		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier ();
+		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+		float fl = 0.f, fr = 0.f;
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			fl = fmaxf (fl, X[((0 * 4 + kg) * 4 + g) * 16 + cc]);         // column `lane` = block lane >> 4 (= kg), c = lane & 15
+			fr = fmaxf (fr, X[((1 * 4 + kg) * 4 + g) * 16 + cc]);
+		}
+		pkf = v2f{fmaxf (pkf.x, fl * scl.un), fmaxf (pkf.y, fr * scr.un)};
+		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier ();
+	};
+
+	// a sample has outgrown a lane's scale: peaks out of the scaled domain, new scales, the lane's ring words rescaled
+	// in place by the (power-of-two) ratio — every word of the four slots; the slot about to be overwritten included
+	auto rescale = [&] (float ml, float mr) __attribute__ ((always_inline)) {
+		flush_pm ();
+		const bool el = __float_as_uint (ml) >= scl.cap, er = __float_as_uint (mr) >= scr.cap;
+		const float ol = scl.sc, orr = scr.sc;
+		if (el) scl.set (ml);
+		if (er) scr.set (mr);
+		if (el || er) {
+			typedef _Float16 h2v __attribute__ ((ext_vector_type (2)));
+			const _Float16 rl = (_Float16) (scl.sc / ol), rr = (_Float16) (scr.sc / orr);      // 1 or 2^-12 and below (0 under 2^-24)
+#pragma unroll 1
+			for (int arr = 0; arr < 4; ++arr) {
+				const _Float16 r = (arr & 1) ? rr : rl;
+				const h2v r2 = h2v{r, r};
+#pragma unroll 1
+				for (int i = 0; i < 8; ++i) {
+					uint4* const p = reinterpret_cast<uint4*> (smem + arr * ARRB + WA + 16 * i);
+					uint4 v = *p;
+					v.x = __builtin_bit_cast (uint32_t, (h2v) (__builtin_bit_cast (h2v, v.x) * r2));
+					v.y = __builtin_bit_cast (uint32_t, (h2v) (__builtin_bit_cast (h2v, v.y) * r2));
+					v.z = __builtin_bit_cast (uint32_t, (h2v) (__builtin_bit_cast (h2v, v.z) * r2));
+					v.w = __builtin_bit_cast (uint32_t, (h2v) (__builtin_bit_cast (h2v, v.w) * r2));
+					*p = v;
+				}
+			}
+		}
+		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier ();
+	};
+
+	// Operands of (block, channel) bc for the products of the step whose window ends in ring slot (U + 3) & 3: window
+	// quarter v sits in slot (U + v) & 3.
+	m16::BFrag B0, B1;
+	m16::f4 y0[3], y1[3];
+#pragma unroll
+	for (int p = 0; p < 3; ++p) { y0[p] = m16::f4{0.f, 0.f, 0.f, 0.f}; y1[p] = m16::f4{0.f, 0.f, 0.f, 0.f}; }
+	auto fetch = [&]<int U> (m16::BFrag& B, int bc) __attribute__ ((always_inline)) {
+		const int b = bc >> 1, ch = bc & 1;
+		const lds_u8* const h = smem + ch * ARRB + b * BLKB;
+		const lds_u8* const l = h + 2 * ARRB;
+		B.h0 = *reinterpret_cast<const uint4*> (h + RA[U]);
+		B.l0 = *reinterpret_cast<const uint4*> (l + RA[U]);
+		B.h1 = *reinterpret_cast<const uint4*> (h + RA[(U + 2) & 3]);
+		B.l1 = *reinterpret_cast<const uint4*> (l + RA[(U + 2) & 3]);
+	};
+	// |max| of the accumulators of (block, channel) bc into pm
+	auto fold = [&] (const m16::f4 (&y)[3], int bc) __attribute__ ((always_inline)) {
+		float m = pm[bc >> 1][bc & 1];
+#pragma unroll
+		for (int p = 0; p < 3; ++p) { m = max3abs (m, y[p][0], y[p][1]); m = max3abs (m, y[p][2], y[p][3]); }
+		pm[bc >> 1][bc & 1] = m;
+	};
+	// the products of the call's last step (nothing left to run under them); every chunk folds its predecessor's accumulators
+	auto products = [&]<int U> () __attribute__ ((always_inline)) {
+		fetch.template operator()<U> (B0, 0);
+#pragma unroll
+		for (int bc = 0; bc < 8; bc += 2) {
+			fetch.template operator()<U> (B1, bc + 1);
+			m16::block (A, B0, y0);
+			fold (y1, (bc + 7) & 7);
+			if (bc + 2 < 8) fetch.template operator()<U> (B0, bc + 2);
+			m16::block (A, B1, y1);
+			fold (y0, bc);
+		}
+		fold (y1, 7);
+	};
+
+	int tile_left = spt;
+	uint32_t tile = p0;
+	int j = 0;
+
+	// max |x| per channel of buffer B: always computed one step early, under the products of the step before
+	float ml = 0.f, mr = 0.f;
+	auto maxabs = [&]<int B> () __attribute__ ((always_inline)) {
+		ml = 0.f; mr = 0.f;
+#pragma unroll
+		for (int n = 0; n < R; n += 2) { ml = max3abs (ml, xq[B][n].x, xq[B][n + 1].x); mr = max3abs (mr, xq[B][n].y, xq[B][n + 1].y); }
+	};
+
+	// one step: the scalar / packed work of step j on buffer U (ring slot U), and — PROD — the products of step j - 1,
+	// interleaved by sched_group_barrier: VPM VALU instructions behind every MFMA
+	auto step = [&]<int U, bool PROD> () __attribute__ ((always_inline)) {
+		v2f (&x)[R] = xq[U];
+		// phase 0 = |x[n - 24]| for the frames of this call: everything but its last 24 frames
+		if (F0 + (int64_t) R * (j + 1) <= a.p0_end) pk0 = v2f{fmaxf (pk0.x, ml), fmaxf (pk0.y, mr)};
+		else {
+			const int64_t lim = a.p0_end - F0 - (int64_t) R * j;
+#pragma unroll
+			for (int n = 0; n < R; ++n) if (n < lim) pk0 = v2f{fmaxf (pk0.x, fabsf (x[n].x)), fmaxf (pk0.y, fabsf (x[n].y))};
+		}
+		if (__builtin_expect (__ballot (__float_as_uint (ml) >= scl.cap || __float_as_uint (mr) >= scr.cap) != 0, 0)) rescale (ml, mr);
+
+		// the stream, three steps ahead (the pointer stops with the segment: the last loads re-read its last line)
+		if (PROD) fetch.template operator()<U> (B0, 0);
+		lp += (j + 3 < n_steps) ? R / 2 : 0;
+		load.template operator()<(U + 3) & 3> ();
+
+		// Eight chunks, one per (block, channel) of the products of step j - 1.  THE SOURCE ORDER IS THE SCHEDULE (this TU
+		// is compiled without the machine schedulers, csrc/Makefile): behind every MFMA one packed or two scalar
+		// instructions of this step's own work, which is what issues for free in an MFMA's shadow (tools/coissue.hip):
+		//   MFMA 0-1: the scale of two frames    2: f16 hi pairs    3-4: lo pairs (v_fma_mix)    5: the next step's maxima
+		//   6-8: |max| of the previous chunk's accumulators    9-17: nine operations of the recurrence
+		// and behind the eighteenth the recurrence's other thirteen.
+		const v2f sc2 = v2f{scl.sc, scr.sc};
+		uint32_t hl[R / 2], hr[R / 2], ll[R / 2], lr[R / 2];
+		float nl = 0.f, nr = 0.f;
+		const v2f (&xn)[R] = xq[(U + 1) & 3];
+		auto chunk = [&]<int BC> (m16::BFrag& Bc, m16::BFrag& Bn, m16::f4 (&yc)[3], m16::f4 (&yp)[3]) __attribute__ ((always_inline)) {
+			constexpr int PB = (BC + 7) & 7;
+			const v2f xa = x[2 * BC], xb = x[2 * BC + 1];
+			KTmp w;
+			if (PROD && BC < 7) fetch.template operator()<U> (Bn, BC + 1);
+#define MTR_M(I) if (PROD) m16::block_mfma<I> (A, Bc, yc)
+			MTR_M (0);  const v2f um = xa * sc2;
+			MTR_M (1);  const v2f vm = xb * sc2;
+			MTR_M (2);  hl[BC] = m16::hi_pair (um.x, vm.x); hr[BC] = m16::hi_pair (um.y, vm.y);
+			MTR_M (3);  ll[BC] = m16::lo_pair (hl[BC], um.x, vm.x);
+			MTR_M (4);  lr[BC] = m16::lo_pair (hr[BC], um.y, vm.y);
+			MTR_M (5);  nl = max3abs (nl, xn[2 * BC].x, xn[2 * BC + 1].x); nr = max3abs (nr, xn[2 * BC].y, xn[2 * BC + 1].y);
+			float m = pm[PB >> 1][PB & 1];
+			MTR_M (6);  if (PROD) { m = max3abs (m, yp[0][0], yp[0][1]); m = max3abs (m, yp[0][2], yp[0][3]); }
+			MTR_M (7);  if (PROD) { m = max3abs (m, yp[1][0], yp[1][1]); m = max3abs (m, yp[1][2], yp[1][3]); }
+			MTR_M (8);  if (PROD) { m = max3abs (m, yp[2][0], yp[2][1]); m = max3abs (m, yp[2][2], yp[2][3]); }
+			if (PROD) asm volatile ("" : "+v"(m));        // consumed here: the maxima must not sink behind the accumulators' next writers
+			pm[PB >> 1][PB & 1] = m;
+			MTR_M (9);  if (EBU) kop<0> (kc, ks, w, xa);
+			MTR_M (10); if (EBU) kop<1> (kc, ks, w, xa);
+			MTR_M (11); if (EBU) kop<2> (kc, ks, w, xa);
+			MTR_M (12); if (EBU) kop<3> (kc, ks, w, xa);
+			MTR_M (13); if (EBU) kop<4> (kc, ks, w, xa);
+			MTR_M (14); if (EBU) kop<5> (kc, ks, w, xa);
+			MTR_M (15); if (EBU) kop<6> (kc, ks, w, xa);
+			MTR_M (16); if (EBU) kop<7> (kc, ks, w, xa);
+			MTR_M (17); if (EBU) kop<8> (kc, ks, w, xa);
+#undef MTR_M
+			if (EBU) {
+				kop<9> (kc, ks, w, xa); kop<10> (kc, ks, w, xa);
+				kop<0> (kc, ks, w, xb); kop<1> (kc, ks, w, xb); kop<2> (kc, ks, w, xb); kop<3> (kc, ks, w, xb);
+				kop<4> (kc, ks, w, xb); kop<5> (kc, ks, w, xb); kop<6> (kc, ks, w, xb); kop<7> (kc, ks, w, xb);
+				kop<8> (kc, ks, w, xb); kop<9> (kc, ks, w, xb); kop<10> (kc, ks, w, xb);
+			}
+		};
+		chunk.template operator()<0> (B0, B1, y0, y1); chunk.template operator()<1> (B1, B0, y1, y0);
+		chunk.template operator()<2> (B0, B1, y0, y1); chunk.template operator()<3> (B1, B0, y1, y0);
+		chunk.template operator()<4> (B0, B1, y0, y1); chunk.template operator()<5> (B1, B0, y1, y0);
+		chunk.template operator()<6> (B0, B1, y0, y1); chunk.template operator()<7> (B1, B0, y1, y0);
+		{
+			uint4* const w = reinterpret_cast<uint4*> (smem + WA + U * 32);
+			w[0]                  = uint4{hl[0], hl[1], hl[2], hl[3]}; w[1]                  = uint4{hl[4], hl[5], hl[6], hl[7]};
+			w[ARRB / 16]          = uint4{hr[0], hr[1], hr[2], hr[3]}; w[ARRB / 16 + 1]      = uint4{hr[4], hr[5], hr[6], hr[7]};
+			w[2 * ARRB / 16]      = uint4{ll[0], ll[1], ll[2], ll[3]}; w[2 * ARRB / 16 + 1]  = uint4{ll[4], ll[5], ll[6], ll[7]};
+			w[3 * ARRB / 16]      = uint4{lr[0], lr[1], lr[2], lr[3]}; w[3 * ARRB / 16 + 1]  = uint4{lr[4], lr[5], lr[6], lr[7]};
+		}
+		asm volatile ("" : "+v"(nl), "+v"(nr));
+		ml = nl; mr = nr;
+		++j;
+		if (EBU && --tile_left == 0) {
+			if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
+			ks.sj = 0;
+			ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);   // ebu_r128_proc.cc:331-334
+			tile_left = spt; ++tile;
+		}
+	};
+
+	// (the first three loads above were steps 0..2; step 0 has no products in front of it)
+	lp -= R / 2;                                                      // `step` advances before it loads
+	maxabs.template operator()<0> ();
+	step.template operator()<0, false> ();
+	while (j + 4 <= n_steps) {
+		step.template operator()<1, true> ();
+		step.template operator()<2, true> ();
+		step.template operator()<3, true> ();
+		step.template operator()<0, true> ();
+	}
+	if (j < n_steps) step.template operator()<1, true> ();
+	if (j < n_steps) step.template operator()<2, true> ();
+	if (j < n_steps) step.template operator()<3, true> ();
+	switch (n_steps & 3) {                                           // the products of the last step
+	case 0:  products.template operator()<0> (); break;
+	case 1:  products.template operator()<1> (); break;
+	case 2:  products.template operator()<2> (); break;
+	default: products.template operator()<3> (); break;
+	}
+	flush_pm ();
+
+	if (live) {
+		atomicMax (&st->tp_call[0], __float_as_uint (fmaxf (pk0.x, pkf.x)));
+		atomicMax (&st->tp_call[1], __float_as_uint (fmaxf (pk0.y, pkf.y)));
+		if (EBU && q == a.n_segs - 1) {
+			st->kz[0] = ks.z1.x; st->kz[1] = ks.z1.y; st->kz[2] = ks.z2.x; st->kz[3] = ks.z2.y;
+			st->kz[4] = ks.z3.x; st->kz[5] = ks.z3.y; st->kz[6] = ks.z4.x; st->kz[7] = ks.z4.y;
+		}
+	}
+}
+
+}  // namespace
+
+size_t mtr_seg_lds_bytes (void) { return LDS_BYTES; }
+
+int mtr_launch_seg (bool ebu, const mtr_seg_args& a, uint32_t n_waves, void* stream)
+{
+	hipStream_t st = (hipStream_t) stream;
+	if (ebu) hipLaunchKernelGGL ((k_seg<true>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);
+	else     hipLaunchKernelGGL ((k_seg<false>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);
+	return hipGetLastError () == hipSuccess ? 0 : -1;
+}

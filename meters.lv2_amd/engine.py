@@ -104,6 +104,7 @@ def _load():
     L.mtr_engine_prune_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_engine_refine_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_engine_layout.argtypes = [vp]
+    L.mtr_engine_seg_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_comm_unique_id.argtypes = [vp]
     L.mtr_comm_init.argtypes = [C.POINTER(vp), i32, i32, vp, i32]
     L.mtr_comm_destroy.argtypes = [vp]
@@ -343,6 +344,12 @@ class Engine:
 
     def layout(self):
         return lib.mtr_engine_layout(self._h)
+
+    def seg_stats(self):
+        """layout 7: (calls whose whole fragments ran k_seg, frames per stream it covered)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib.mtr_engine_seg_stats(self._h, C.byref(a), C.byref(b)), "seg_stats")
+        return a.value, b.value
 
     def reduce(self, comm, hist_ptr, max_ptr, stream=0):
         """aggregate_device + the RCCL all-reduce across the ranks of `comm` (a Comm), in place, on `stream`."""

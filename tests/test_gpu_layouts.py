@@ -1,6 +1,7 @@
-"""Every fused-kernel variant (layout 1: wave per segment; 2: wave-specialised; 3: wave-specialised with
-rotating roles; dense vs mirror-symmetric interpolator) must give the same record, and each must match
-the oracle within the tolerances of tests/test_gpu_parity.py."""
+"""Every K-weighting + true-peak kernel the library ships — layout 3 (the exact-f32 VALU interpolator, mirror-symmetric
+and dense form), layout 6 (matrix pipe at f32 grade, wave per segment) and layout 7 (the same with lane = segment for the
+calls that fit it) — must give the same record, and each must match the oracle within the tolerances of
+tests/test_gpu_parity.py.  Layouts 1, 2 and 5 of rounds 1-2 are gone: asking for them is an argument error."""
 import os
 import sys
 
@@ -13,8 +14,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 from make_golden import tri_noise  # noqa: E402
 
-VARIANTS = [dict(tune_layout=1, tune_run=13), dict(tune_layout=1, tune_run=39), dict(tune_layout=2),
-            dict(tune_layout=2, tune_fir=1), dict(tune_layout=3)]
+VARIANTS = [dict(tune_layout=3), dict(tune_layout=3, tune_fir=1), dict(tune_layout=6), dict(tune_layout=7)]
+
+
+def test_retired_layouts_are_argument_errors(M):
+    for kw in (dict(tune_layout=1), dict(tune_layout=2), dict(tune_layout=5), dict(tune_layout=8), dict(tune_fir=3),
+               dict(tune_run=13)):
+        with pytest.raises(M.EngineError):
+            M.Engine(1, 48000.0, M.METER_EBU | M.METER_TRUEPEAK, **kw)
 
 
 @pytest.fixture(scope="module")

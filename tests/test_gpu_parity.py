@@ -228,7 +228,7 @@ def test_edge_cases(M):
     with pytest.raises(M.EngineError):
         M.Engine(1, 48000.0, 0x100)                          # a bit that is no meter
     with pytest.raises(M.EngineError):
-        M.Engine(1, 48000.0, M.METER_EBU, tune_layout=5)     # the matrix-pipe layout needs TRUEPEAK
+        M.Engine(1, 48000.0, M.METER_EBU, tune_layout=6)     # the matrix-pipe layouts need TRUEPEAK
     with pytest.raises(M.EngineError):
         M.Engine(1, 48000.0, M.METER_DR14 | M.METER_BITSTATS)   # stereo and mono-only meters do not mix
 

@@ -1,0 +1,184 @@
+"""Layout 7 (mtr_seg.hip): K-weighting + true peak with lane = time segment — the batch path.
+
+Same arithmetic as layout 6 (the reference's K-weighting recurrence in f32; the 4x interpolator on the matrix pipe at
+f32 grade), another decomposition: a lane walks a whole time segment of a stream 16 frames per step, segments that do
+not start the call are warmed up over 0.2 s, the scale of the f16 halves is per lane and only ever shrinks, whole 50 ms
+fragments go through k_seg and the rest of the call through k_kwtp16.  The bar is the one layouts 3 and 6 are held to
+(tests/test_gpu_parity.py): fragment powers 2e-5 relative, M / S 1e-3 dB, integrated +-0.01 dB, at most two histogram
+points in a neighbouring bin, true peaks 2e-6 relative of the oracle (= ebu_r128_proc / Resampler + process_max).
+
+`tune_segments` forces the kernel onto batches far too small to be worth it, which is how these tests reach it with a
+handful of streams; `seg_stats` says which calls really took it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_golden import tri_noise  # noqa: E402
+
+TP_RTOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def M():
+    import meters.lv2_amd as m
+    return m
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+
+
+def _run(M, x, calls, fs=48000.0, meters=None, **kw):
+    meters = meters if meters is not None else (M.METER_EBU | M.METER_TRUEPEAK)
+    with M.Engine(x.shape[0], fs, meters, **kw) as e:
+        if meters & M.METER_EBU:
+            e.integr_start()
+        pos, per_call, frags = 0, [], []
+        for n in calls:
+            e.process(x[:, pos:pos + n])
+            per_call.append(np.array([[r.truepeak_call[0], r.truepeak_call[1]] for r in e.results()], np.float32))
+            if meters & M.METER_EBU:
+                frags.append(e.fragment_powers())
+            pos += n
+        o9 = e.out9() if meters & M.METER_EBU else None
+        hist = e.histograms() if meters & M.METER_EBU else None
+        fr = np.concatenate(frags, 1) if frags else None
+        return dict(o9=o9, tp=e.truepeak(), per_call=np.stack(per_call), hist=hist, frag=fr, seg=e.seg_stats(), layout=e.layout())
+
+
+def _check_ebu(got, ref, s, tag):
+    assert np.allclose(got["frag"][s], ref["frag_power"], rtol=2e-5), (tag, s, np.abs(got["frag"][s] / ref["frag_power"] - 1).max())
+    assert np.allclose(got["o9"][s, :4], ref["out9"][:4], atol=1e-3), (tag, s, got["o9"][s], ref["out9"])
+    assert abs(got["o9"][s, 4] - ref["out9"][4]) <= 0.01, (tag, s)
+    assert np.abs(got["hist"][0][s] - ref["hist_M"]).sum() // 2 <= 2, (tag, s)
+    assert np.abs(got["hist"][1][s] - ref["hist_S"]).sum() // 2 <= 2, (tag, s)
+
+
+@pytest.mark.parametrize("fs", [48000.0, 96000.0, 32000.0])
+@pytest.mark.parametrize("segs", [1, 2, 5])
+def test_seg_matches_oracle(M, oracle, fs, segs):
+    """Whole-fragment calls, calls with a tail behind the last fragment, several calls in a row (the K-filter state and
+    the interpolator's history cross the call boundary), segments of unequal length (the shorter ones start a tile early)."""
+    fragm = int(fs) // 20
+    calls = [fragm * 37, fragm * 30 + 777, fragm * 3 - 777, fragm * 26]           # the 2nd call ends inside a fragment ...
+    T = sum(calls)
+    S = 5
+    x = np.stack([tri_noise(T, 700 + s, 2.0 ** -(s % 3), period=72000) for s in range(S)])
+    got = _run(M, x, calls, fs, tune_segments=segs, tune_layout=7)
+    assert got["layout"] == 7
+    # ... so the 3rd starts inside one and runs layout 6; calls 1, 2 and 4 start on a boundary
+    assert got["seg"][0] == 3 and got["seg"][1] == fragm * (37 + 30 + 26), got["seg"]
+    for s in range(S):
+        _check_ebu(got, oracle.ebu(x[s], fs, fragm, want_frag=True), s, (fs, segs))
+        assert _rel(got["tp"][s], oracle.tp(x[s], fs, 8192)).max() <= TP_RTOL, (s, got["tp"][s])
+    # per call against layout 6 (its per-call peaks are held to TruePeakdsp::process_max block by block elsewhere)
+    ref6 = _run(M, x, calls, fs, tune_segments=0, tune_layout=6)
+    assert ref6["seg"][0] == 0 and ref6["layout"] == 6
+    assert _rel(got["per_call"], ref6["per_call"]).max() <= TP_RTOL, _rel(got["per_call"], ref6["per_call"]).max()
+
+
+def test_seg_not_taken_where_it_does_not_fit(M, oracle):
+    """44.1 kHz fragments are 2205 frames (not a multiple of 16), a call that starts inside a fragment, an odd stride, a
+    small batch without tune_segments, pruning: layout 6 serves all of them, and the results are the usual ones."""
+    T = 44100 * 4
+    x = np.stack([tri_noise(T, 30 + s, 0.5, period=50000) for s in range(3)])
+    got = _run(M, x, [T], 44100.0, tune_segments=4, tune_layout=7)
+    assert got["seg"][0] == 0
+    for s in range(3):
+        _check_ebu(got, oracle.ebu(x[s], 44100.0, 2205, want_frag=True), s, "44k1")
+    T = 48000 * 4
+    x = np.stack([tri_noise(T, 60 + s, 0.5, period=50000) for s in range(3)])
+    assert _run(M, x, [T])["seg"][0] == 0                                     # three streams do not fill 65536 lanes
+    assert _run(M, x, [T], tune_prune=1, tune_segments=2)["seg"][0] == 0      # pruning is a layout 6 feature
+    assert _run(M, x, [1000, T - 1000], tune_segments=2)["seg"][0] == 0       # 1000 < one fragment, then off the boundary
+    got = _run(M, x, [2400 * 3, T - 2400 * 3], tune_segments=2)
+    assert got["seg"] == (2, T)
+    with M.Engine(3, 48000.0, M.METER_EBU | M.METER_TRUEPEAK, tune_segments=2) as e:
+        import torch
+        buf = torch.zeros(3 * (T + 1) * 2 + 2, dtype=torch.float32, device="cuda")
+        view = buf[: 3 * (T + 1) * 2].view(3, T + 1, 2)
+        view[:, :T] = torch.from_numpy(x).cuda()
+        e.process_device(buf.data_ptr(), T, T + 1)                           # odd stride: streams 1 and 3 sit on 8 bytes
+        torch.cuda.synchronize()
+        assert e.seg_stats()[0] == 0
+        tp = e.truepeak()
+    for s in range(3):
+        assert _rel(tp[s], oracle.tp(x[s], 48000.0, 8192)).max() <= TP_RTOL
+
+
+def test_seg_edge_signals(M, oracle):
+    """The per-lane scale: silence then programme, level jumps of 2^40 up and down (the ring is rescaled in place),
+    streams from 2^-60 to 1e30, channels 180 dB apart, impulses next to fragment and segment boundaries, the fs/4
+    pattern (+3.1056 dBTP), Inf and NaN samples."""
+    import _signals as sig
+    T = 2400 * 60
+    n = sig.lcg_noise(T, 11, 1.0).astype(np.float32)
+    spike = np.zeros((T, 2), np.float32)
+    spike[2399, 0] = 1.0; spike[2400, 1] = -1.0; spike[T - 1, 0] = 0.5; spike[2400 * 30 - 1, 1] = 0.25; spike[2400 * 30, 0] = -0.75
+    g3 = np.tile(np.array([1, 1, -1, -1], np.float32), T // 4)[:, None].repeat(2, 1)
+    quiet, tiny, hot, huge = (n * np.float32(2.0 ** -20), n * np.float32(2.0 ** -60), n * np.float32(8.0), n * np.float32(1e30))
+    up = n.copy(); up[:70001] *= np.float32(2.0 ** -40)
+    down = n.copy(); down[70001:] *= np.float32(2.0 ** -40)
+    late = n.copy(); late[:100003] = 0.0
+    lr = n.copy(); lr[:, 1] *= np.float32(2.0 ** -30)
+    ramp = n * (np.float32(2.0) ** (np.arange(T, dtype=np.float32) / 4800.0 - 28.0))[:, None]       # + 6 dB every 100 ms: many rescales
+    x = np.stack([spike, g3, np.zeros((T, 2), np.float32), quiet, tiny, hot, huge, up, down, late, lr, ramp])
+    for segs in (1, 3):
+        got = _run(M, x, [T], tune_segments=segs, tune_layout=7)
+        assert got["seg"][0] == 1
+        ref = _run(M, x, [T], tune_layout=3)
+        assert np.all(got["tp"][2] == 0.0)
+        m = ref["per_call"] > 0
+        assert np.all((got["per_call"] > 0) == m)
+        assert _rel(got["per_call"][m], ref["per_call"][m]).max() <= TP_RTOL, _rel(got["per_call"][m], ref["per_call"][m]).max()
+        for s in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+            assert _rel(got["tp"][s], oracle.tp(x[s], 48000.0, 8192)).max() <= TP_RTOL, (segs, s, got["tp"][s])
+        assert abs(20 * np.log10(got["tp"][1, 0]) - 3.1056) < 1e-3
+        # loudness of the well-conditioned streams (the others are held by the fuzz / parity files on layout 6's arithmetic)
+        for s in (5, 10):
+            _check_ebu(got, oracle.ebu(x[s], 48000.0, 2400, want_frag=True), s, ("edge", segs))
+    # non-finite samples: an Inf is the peak of its channel, a NaN is skipped like the reference's `if (v > m)` skips it
+    bad = np.stack([n * np.float32(0.25), n * np.float32(0.25)])
+    bad[0, 50000, 0] = np.inf
+    bad[1, 50000, 1] = np.nan
+    got = _run(M, bad, [T], tune_segments=3, tune_layout=7)
+    ref = _run(M, bad, [T], tune_layout=6)
+    assert got["tp"][0, 0] == np.inf and np.isfinite(got["tp"][0, 1])
+    assert np.all(np.isfinite(got["tp"][1]))
+    assert _rel(got["tp"][0, 1], ref["tp"][0, 1]) <= TP_RTOL and _rel(got["tp"][1, 0], ref["tp"][1, 0]) <= TP_RTOL
+    # (the NaN's own channel: both layouts drop the outputs of the 16-frame columns the NaN reaches)
+    assert _rel(got["tp"][1, 1], ref["tp"][1, 1]) <= 1e-2
+
+
+def test_seg_truepeak_only_and_ragged_batch(M, oracle):
+    """No EBU: no K-filter, no warm-up.  67 streams x 3 segments = 201 units: the last wave has 9 live lanes."""
+    T = 2400 * 40 + 123
+    S = 67
+    x = np.stack([tri_noise(T, 900 + s, 0.5 + 0.4 * (s % 2), period=30000) for s in range(S)])
+    got = _run(M, x, [T], meters=M.METER_TRUEPEAK, tune_segments=3, tune_layout=7)
+    assert got["seg"] == (1, 2400 * 40)
+    for s in range(0, S, 5):
+        assert _rel(got["tp"][s], oracle.tp(x[s], 48000.0, 8192)).max() <= TP_RTOL, s
+    both = _run(M, x, [T], tune_segments=3, tune_layout=7)
+    assert _rel(both["tp"], got["tp"]).max() == 0.0                      # the interpolator does not depend on the K-filter
+    for s in range(0, S, 11):
+        _check_ebu(both, oracle.ebu(x[s], 48000.0, 2400, want_frag=True), s, "ragged")
+
+
+def test_seg_is_deterministic_and_segmentation_independent(M):
+    T = 2400 * 48
+    x = np.stack([tri_noise(T, 77 + s, 0.5, period=30000) for s in range(9)])
+    a = _run(M, x, [T], tune_segments=4, tune_layout=7)
+    b = _run(M, x, [T], tune_segments=4, tune_layout=7)
+    assert np.array_equal(a["frag"], b["frag"]) and np.array_equal(a["tp"], b["tp"]) and np.array_equal(a["o9"], b["o9"])
+    c = _run(M, x, [T], tune_segments=1, tune_layout=7)
+    assert np.allclose(a["frag"], c["frag"], rtol=2e-6)                  # warm-up vs carried state: far below the 2e-5 gate
+    assert _rel(a["tp"], c["tp"]).max() <= 1e-6                           # (the scale history of a lane differs)
