@@ -250,12 +250,12 @@ def main():
         if tq["calls"] and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
             k_ms = tq["ms_fused"] / tq["calls"]
             achieved = S * T * BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
-            kname = {6: "k_kwtp16", 5: "k_kwtp", 4: "k_kw"}.get(layout, "k_fused2")
+            kname = "k_seg" if (layout == 7 and eng.seg_stats()[0]) else {7: "k_kwtp16", 6: "k_kwtp16", 4: "k_kw"}.get(layout, "k_fused2")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(args.meters, S, T, layout),
                                "kernel": kname, "kernel_ms": k_ms, "gate_ms": tq["ms_gate"] / tq["calls"],
                                "algorithmic_bytes_per_launch": S * T * BYTES_PER_FRAME}
-            if layout == 6:
+            if layout in (6, 7):
                 # what binds: issue slots of the SIMDs.  Per stereo frame the kernel issues 18 x 2 / 256 MFMAs
                 # (16x16x32 f16, 16 cycles of the matrix pipe each) and ~37 VALU instructions (~23 without the K-filter);
                 # packed-f32 VALU work and MFMAs do not overlap on a SIMD (tools/coissue.hip), so the two add up.

@@ -351,7 +351,9 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 
 		// the stream, three steps ahead (the pointer stops with the segment: the last loads re-read its last line)
 		if (PROD) fetch.template operator()<U> (B0, 0);
+#ifndef MTR_SEG_DBG_NOADV                                         /* (elimination runs, tools/seg_ab.sh: the same line over and over) */
 		lp += (j + 3 < n_steps) ? R / 2 : 0;
+#endif
 		load.template operator()<(U + 3) & 3> ();
 
 		// Eight chunks, one per (block, channel) of the products of step j - 1.  THE SOURCE ORDER IS THE SCHEDULE (this TU
@@ -369,7 +371,11 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 			const v2f xa = x[2 * BC], xb = x[2 * BC + 1];
 			KTmp w;
 			if (PROD && BC < 7) fetch.template operator()<U> (Bn, BC + 1);
+#ifdef MTR_SEG_DBG_NOPROD                                        /* (elimination runs: no products) */
+#define MTR_M(I)
+#else
 #define MTR_M(I) if (PROD) m16::block_mfma<I> (A, Bc, yc)
+#endif
 			MTR_M (0);  const v2f um = xa * sc2;
 			MTR_M (1);  const v2f vm = xb * sc2;
 			MTR_M (2);  hl[BC] = m16::hi_pair (um.x, vm.x); hr[BC] = m16::hi_pair (um.y, vm.y);
