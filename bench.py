@@ -10,7 +10,8 @@ RCCL traffic is the final all-reduce of the two 751-bin loudness histograms (sum
 peak / max-loudness values (max), done once per step by mtr_engine_reduce() — RCCL inside the C ABI
 (torch.distributed only ships the 128-byte communicator id and provides the barrier).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                            torch.distributed.run on 127.0.0.1, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  `value` counts channel-samples/s (2 per stereo frame), whole job.
@@ -103,6 +104,44 @@ def committed_traffic(meters, S, T, layout):
     return None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: become `torch.distributed.run --nproc-per-node N bench.py ...`
+    (the command the driver itself uses), rendezvous on 127.0.0.1 and a free port.  Rank 0 prints the one JSON line."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_run(args, rank, world):
+    """MTR_BENCH_DRY_RUN=1: the launcher logic without a GPU (tests/test_bench_launch.py) — ranks rendezvous over gloo, shard
+    the job's streams, agree on the shards and rank 0 prints them.  Never a measurement."""
+    import torch
+    import torch.distributed as dist
+    from meters.lv2_amd import dist as mdist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    first, count = mdist.shard(args.streams * world, world, rank)
+    mine = torch.tensor([rank, int(os.environ.get("LOCAL_RANK", "0")), first, count], dtype=torch.int64)
+    rows = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(rows, mine)
+        dist.barrier()
+    else:
+        rows = [mine]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "streams_per_gpu": args.streams,
+                          "ranks": [[int(v) for v in r] for r in rows]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,18 +161,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                                 # does not return
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if os.environ.get("MTR_BENCH_DRY_RUN") == "1":
+        return dry_run(args, rank, world)
+
     import numpy as np
     import torch
     import torch.distributed as dist
     import meters.lv2_amd as M
     from meters.lv2_amd import dist as mdist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU path")
     # MTR_BENCH_SHARED_GPU=1: every rank on GPU 0 with the gloo backend — a rehearsal of the N > 1 control

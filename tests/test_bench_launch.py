@@ -1,0 +1,43 @@
+"""bench.py must be launchable for N > 1 exactly the way the driver launches it for N = 1 — `python bench.py --gpus N` —
+and under torch.distributed.run (the N > 1 line used to exit with "launch with torch.distributed.run").
+MTR_BENCH_DRY_RUN=1 runs the launcher logic only: self-launch, rendezvous on 127.0.0.1, shard arithmetic; no GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, **env):
+    e = dict(os.environ, MTR_BENCH_DRY_RUN="1", **env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                         # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_plain_python_launch_spawns_the_ranks():
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--streams", "101"])
+    assert d["dry_run"] and d["n_gpus"] == 2
+    rows = sorted(d["ranks"])
+    assert [r[0] for r in rows] == [0, 1] and [r[1] for r in rows] == [0, 1]          # rank, local rank = GPU ordinal
+    # weak scaling: every rank owns `--streams` streams, contiguous and disjoint
+    assert [r[3] for r in rows] == [101, 101] and [r[2] for r in rows] == [0, 101]
+
+
+def test_torchrun_launch_and_single_rank():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+              "--master-port", "29613", "bench.py", "--gpus", "3", "--streams", "7"])
+    assert d["n_gpus"] == 3 and sorted(r[2] for r in d["ranks"]) == [0, 7, 14]
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--streams", "5"])
+    assert d["n_gpus"] == 1 and d["ranks"] == [[0, 0, 0, 5]]
+
+
+def test_rank_count_mismatch_is_an_error():
+    e = dict(os.environ, MTR_BENCH_DRY_RUN="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr
