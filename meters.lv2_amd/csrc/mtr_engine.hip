@@ -613,7 +613,7 @@ static SegPlan seg_plan (const mtr_engine* e, const float* d_audio, uint64_t N, 
 	const uint64_t tiles = N / e->fragm;
 	if (tiles == 0 || tiles > 0x7fffffffull / (e->fragm / MTR_SEG_STEP)) return sp;
 	const uint32_t spt = e->fragm / MTR_SEG_STEP;
-	const uint32_t warm_steps = ebu ? ((uint32_t) std::ceil (MTR_WARM_SEC * e->cfg.sample_rate / (float) MTR_SEG_STEP) + 3) / 4 * 4 : 0;
+	const uint32_t warm_steps = ebu ? ((uint32_t) std::ceil (MTR_SEG_WARM_SEC * e->cfg.sample_rate / (float) MTR_SEG_STEP) + 3) / 4 * 4 : 0;
 	const uint32_t warm_tiles = (warm_steps * MTR_SEG_STEP + e->fragm - 1) / e->fragm;
 	const uint64_t S = e->cfg.n_streams;
 	uint64_t gmax = ebu ? tiles / (warm_tiles + 2) : tiles;

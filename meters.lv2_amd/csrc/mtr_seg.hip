@@ -16,8 +16,8 @@
 //     not start the call is warmed up over the 0.2 s in front of it (slowest pole 0.99502 per sample: 1e-21 — what
 //     k_kwtp16's own time segments do), segment 0 starts from the carried state;
 //   * the 16 new frames of a lane are ONE column of the block-Toeplitz product: rows = the 16 outputs, window = the
-//     lane's last 64 samples, which sit in a four-slot ring in LDS (f16 hi / lo words, 144 bytes per column and
-//     array: conflict-free ds_read_b128 / ds_write_b128).  One step = 64 columns = 4 blocks x 2 channels x 18 MFMAs;
+//     lane's last 64 samples, which sit in a four-slot ring in LDS (f16 hi / lo words, 128 bytes per column and
+//     array, 16-byte chunks XOR-swizzled by the column: conflict-free ds_read_b128 / ds_write_b128).  One step = 64 columns = 4 blocks x 2 channels x 18 MFMAs;
 //   * the scale of a column is its lane's own: a power of two that puts the segment's running maximum into
 //     [2^3, 2^15) — it only ever shrinks, and when it must (a sample 2^12 above what the scale was made for) the lane's
 //     ring words are rescaled in place (exact: a power of two) and the peaks so far leave the scaled domain.  An Inf
@@ -38,10 +38,21 @@
 #include "mtr_mfma16_fir.h"
 #include "mtr_wave.h"
 
+// -DMTR_SEG_PROF: shader cycles per part of a step, summed over one wave's main loop (tools/seg_prof.py)
+#ifdef MTR_SEG_PROF
+__device__ unsigned long long g_seg_prof[8];
+#define SPROF_NOW(v) unsigned long long v; asm volatile ("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define SPROF_ADD(i, d) sprof_[i] += (d)
+#else
+#define SPROF_NOW(v)
+#define SPROF_ADD(i, d)
+#endif
+
 namespace {
 
 constexpr int R     = MTR_SEG_STEP;          // frames per lane and step = one MFMA column
-constexpr int COLB  = 144;                   // bytes per column and array: 4 ring slots x 32 + 16 of padding (bank spread)
+constexpr int COLB  = 128;                   // bytes per column and array: 4 ring slots x 32; the eight 16-byte chunks of a column sit at
+                                             // chunk ^ (column & 7): conflict-free in ds_read_b128's 16-lane groups and ds_write_b128's 8-lane groups
 constexpr int ARRB  = 64 * COLB;             // one array: HL | HR | LL | LR
 constexpr int BLKB  = 16 * COLB;             // 16 columns = one MFMA block
 constexpr int XCHG  = 4 * ARRB;              // exchange area: float [2 ch][4 blocks][4 kg][16 c]
@@ -145,10 +156,29 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	const bool warm = EBU && q > 0;
 	const float4* lp = reinterpret_cast<const float4*> (src + F0 - (warm ? (int64_t) a.warm_steps * R : 0));
 	v2f xq[4][R];
+#ifdef MTR_SEG_DBG_COOP
+	// (timing probe only, WRONG DATA: instruction i reads whole lines — lanes 8 k .. 8 k + 7 the eight chunks of the line of
+	// lane 8 i + k — to price the address pipeline's share of a step: 64 line fragments per instruction against 8 lines)
+	const float4* lpc[R / 2];
+#pragma unroll
+	for (int i = 0; i < R / 2; ++i) {
+		const int from = 8 * i + (lane >> 3);
+		const uint64_t pv = reinterpret_cast<uint64_t> (lp);
+		const uint32_t lo = (uint32_t) __shfl ((int) (uint32_t) pv, from), hi = (uint32_t) __shfl ((int) (uint32_t) (pv >> 32), from);
+		lpc[i] = reinterpret_cast<const float4*> (((uint64_t) hi << 32) | lo) + (lane & 7);
+	}
+	const float4* const lp0 = lp;
+	auto load = [&]<int B> () __attribute__ ((always_inline)) {
+		const int64_t d = lp - lp0;
+#pragma unroll
+		for (int i = 0; i < R / 2; ++i) { const float4 v = lpc[i][d]; xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w}; }
+	};
+#else
 	auto load = [&]<int B> () __attribute__ ((always_inline)) {
 #pragma unroll
 		for (int i = 0; i < R / 2; ++i) { const float4 v = lp[i]; xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w}; }
 	};
+#endif
 	load.template operator()<0> (); lp += R / 2;
 	load.template operator()<1> (); lp += R / 2;
 	load.template operator()<2> (); lp += R / 2;
@@ -175,8 +205,11 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	const int cc = lane & 15, kg = lane >> 4;
 	int RA[4];                                                        // operand read address of window quarter v, this lane
 #pragma unroll
-	for (int v = 0; v < 4; ++v) RA[v] = cc * COLB + (kg & 1) * 16 + ((v + (kg >> 1)) & 3) * 32;
+	for (int v = 0; v < 4; ++v) RA[v] = cc * COLB + ((((kg & 1) + 2 * ((v + (kg >> 1)) & 3)) ^ (cc & 7)) * 16);
 	const int WA = lane * COLB;                                       // this lane's column
+	int WS[4];                                                        // ... and where the first half of ring slot s sits in it (the second: ^ 16)
+#pragma unroll
+	for (int sl = 0; sl < 4; ++sl) WS[sl] = WA + (((2 * sl) ^ (lane & 7)) * 16);
 
 	Scale scl, scr;
 	v2f pk0 = v2f{0.f, 0.f};                                           // phase 0: max |x[n - 24]|, exact
@@ -194,15 +227,16 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 			m16::split_pair (u.x, v.x, hl[i], ll[i]);
 			m16::split_pair (u.y, v.y, hr[i], lr[i]);
 		}
-		lds_u8* const w = smem + WA + slot * 32;
-		*reinterpret_cast<uint4*> (w)                 = uint4{hl[0], hl[1], hl[2], hl[3]};
-		*reinterpret_cast<uint4*> (w + 16)            = uint4{hl[4], hl[5], hl[6], hl[7]};
-		*reinterpret_cast<uint4*> (w + ARRB)          = uint4{hr[0], hr[1], hr[2], hr[3]};
-		*reinterpret_cast<uint4*> (w + ARRB + 16)     = uint4{hr[4], hr[5], hr[6], hr[7]};
-		*reinterpret_cast<uint4*> (w + 2 * ARRB)      = uint4{ll[0], ll[1], ll[2], ll[3]};
-		*reinterpret_cast<uint4*> (w + 2 * ARRB + 16) = uint4{ll[4], ll[5], ll[6], ll[7]};
-		*reinterpret_cast<uint4*> (w + 3 * ARRB)      = uint4{lr[0], lr[1], lr[2], lr[3]};
-		*reinterpret_cast<uint4*> (w + 3 * ARRB + 16) = uint4{lr[4], lr[5], lr[6], lr[7]};
+		lds_u8* const w0 = smem + WS[slot];
+		lds_u8* const w1 = smem + (WS[slot] ^ 16);
+		*reinterpret_cast<uint4*> (w0)            = uint4{hl[0], hl[1], hl[2], hl[3]};
+		*reinterpret_cast<uint4*> (w1)            = uint4{hl[4], hl[5], hl[6], hl[7]};
+		*reinterpret_cast<uint4*> (w0 + ARRB)     = uint4{hr[0], hr[1], hr[2], hr[3]};
+		*reinterpret_cast<uint4*> (w1 + ARRB)     = uint4{hr[4], hr[5], hr[6], hr[7]};
+		*reinterpret_cast<uint4*> (w0 + 2 * ARRB) = uint4{ll[0], ll[1], ll[2], ll[3]};
+		*reinterpret_cast<uint4*> (w1 + 2 * ARRB) = uint4{ll[4], ll[5], ll[6], ll[7]};
+		*reinterpret_cast<uint4*> (w0 + 3 * ARRB) = uint4{lr[0], lr[1], lr[2], lr[3]};
+		*reinterpret_cast<uint4*> (w1 + 3 * ARRB) = uint4{lr[4], lr[5], lr[6], lr[7]};
 	};
 
 	{
@@ -338,8 +372,12 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 
 	// one step: the scalar / packed work of step j on buffer U (ring slot U), and — PROD — the products of step j - 1,
 	// interleaved by sched_group_barrier: VPM VALU instructions behind every MFMA
+#ifdef MTR_SEG_PROF
+	unsigned long long sprof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
 	auto step = [&]<int U, bool PROD> () __attribute__ ((always_inline)) {
 		v2f (&x)[R] = xq[U];
+		SPROF_NOW (c0_);
 		// phase 0 = |x[n - 24]| for the frames of this call: everything but its last 24 frames
 		if (F0 + (int64_t) R * (j + 1) <= a.p0_end) pk0 = v2f{fmaxf (pk0.x, ml), fmaxf (pk0.y, mr)};
 		else {
@@ -350,11 +388,11 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		if (__builtin_expect (__ballot (__float_as_uint (ml) >= scl.cap || __float_as_uint (mr) >= scr.cap) != 0, 0)) rescale (ml, mr);
 
 		// the stream, three steps ahead (the pointer stops with the segment: the last loads re-read its last line)
-		if (PROD) fetch.template operator()<U> (B0, 0);
 #ifndef MTR_SEG_DBG_NOADV                                         /* (elimination runs, tools/seg_ab.sh: the same line over and over) */
 		lp += (j + 3 < n_steps) ? R / 2 : 0;
 #endif
 		load.template operator()<(U + 3) & 3> ();
+		SPROF_NOW (c1_); SPROF_ADD (0, c1_ - c0_);
 
 		// Eight chunks, one per (block, channel) of the products of step j - 1.  THE SOURCE ORDER IS THE SCHEDULE (this TU
 		// is compiled without the machine schedulers, csrc/Makefile): behind every MFMA one packed or two scalar
@@ -388,15 +426,27 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 			MTR_M (8);  if (PROD) { m = max3abs (m, yp[2][0], yp[2][1]); m = max3abs (m, yp[2][2], yp[2][3]); }
 			if (PROD) asm volatile ("" : "+v"(m));        // consumed here: the maxima must not sink behind the accumulators' next writers
 			pm[PB >> 1][PB & 1] = m;
+			// The ring stores of this step ride in the last two chunks — behind the last operand fetch that still reads the
+			// slot they overwrite (chunk 6 fetches chunk 7's) — and the next step's first operands are fetched behind them:
+			// neither the stores' VGPR transfer nor the fetch's latency is left for the step's head and tail.
+#define MTR_ST(ARR, W_) \
+			if constexpr (BC == 6) *reinterpret_cast<uint4*> (smem + WS[U] + (ARR) * ARRB) = uint4{W_[0], W_[1], W_[2], W_[3]}; \
+			if constexpr (BC == 7) *reinterpret_cast<uint4*> (smem + (WS[U] ^ 16) + (ARR) * ARRB) = uint4{W_[4], W_[5], W_[6], W_[7]}
 			MTR_M (9);  if (EBU) kop<0> (kc, ks, w, xa);
 			MTR_M (10); if (EBU) kop<1> (kc, ks, w, xa);
+			MTR_ST (0, hl);
 			MTR_M (11); if (EBU) kop<2> (kc, ks, w, xa);
 			MTR_M (12); if (EBU) kop<3> (kc, ks, w, xa);
+			MTR_ST (1, hr);
 			MTR_M (13); if (EBU) kop<4> (kc, ks, w, xa);
 			MTR_M (14); if (EBU) kop<5> (kc, ks, w, xa);
+			MTR_ST (2, ll);
 			MTR_M (15); if (EBU) kop<6> (kc, ks, w, xa);
 			MTR_M (16); if (EBU) kop<7> (kc, ks, w, xa);
+			MTR_ST (3, lr);
+			if constexpr (BC == 7) fetch.template operator()<(U + 1) & 3> (Bn, 0);      // (Bn of the last chunk = B0 of the next step)
 			MTR_M (17); if (EBU) kop<8> (kc, ks, w, xa);
+#undef MTR_ST
 #undef MTR_M
 			if (EBU) {
 				kop<9> (kc, ks, w, xa); kop<10> (kc, ks, w, xa);
@@ -405,17 +455,15 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 				kop<8> (kc, ks, w, xb); kop<9> (kc, ks, w, xb); kop<10> (kc, ks, w, xb);
 			}
 		};
-		chunk.template operator()<0> (B0, B1, y0, y1); chunk.template operator()<1> (B1, B0, y1, y0);
+		chunk.template operator()<0> (B0, B1, y0, y1);
+		SPROF_NOW (c2_); SPROF_ADD (1, c2_ - c1_);
+		chunk.template operator()<1> (B1, B0, y1, y0);
 		chunk.template operator()<2> (B0, B1, y0, y1); chunk.template operator()<3> (B1, B0, y1, y0);
 		chunk.template operator()<4> (B0, B1, y0, y1); chunk.template operator()<5> (B1, B0, y1, y0);
-		chunk.template operator()<6> (B0, B1, y0, y1); chunk.template operator()<7> (B1, B0, y1, y0);
-		{
-			uint4* const w = reinterpret_cast<uint4*> (smem + WA + U * 32);
-			w[0]                  = uint4{hl[0], hl[1], hl[2], hl[3]}; w[1]                  = uint4{hl[4], hl[5], hl[6], hl[7]};
-			w[ARRB / 16]          = uint4{hr[0], hr[1], hr[2], hr[3]}; w[ARRB / 16 + 1]      = uint4{hr[4], hr[5], hr[6], hr[7]};
-			w[2 * ARRB / 16]      = uint4{ll[0], ll[1], ll[2], ll[3]}; w[2 * ARRB / 16 + 1]  = uint4{ll[4], ll[5], ll[6], ll[7]};
-			w[3 * ARRB / 16]      = uint4{lr[0], lr[1], lr[2], lr[3]}; w[3 * ARRB / 16 + 1]  = uint4{lr[4], lr[5], lr[6], lr[7]};
-		}
+		chunk.template operator()<6> (B0, B1, y0, y1);
+		SPROF_NOW (c3_); SPROF_ADD (2, c3_ - c2_);
+		chunk.template operator()<7> (B1, B0, y1, y0);
+		SPROF_NOW (c4_); SPROF_ADD (3, c4_ - c3_);
 		asm volatile ("" : "+v"(nl), "+v"(nr));
 		ml = nl; mr = nr;
 		++j;
@@ -425,6 +473,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 			ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);   // ebu_r128_proc.cc:331-334
 			tile_left = spt; ++tile;
 		}
+		SPROF_NOW (c5_); SPROF_ADD (4, c5_ - c4_); SPROF_ADD (5, c5_ - c0_); SPROF_ADD (6, 1);
 	};
 
 	// (the first three loads above were steps 0..2; step 0 has no products in front of it)
@@ -447,6 +496,9 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	default: products.template operator()<3> (); break;
 	}
 	flush_pm ();
+#ifdef MTR_SEG_PROF
+	if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 8; ++i) g_seg_prof[i] = sprof_[i];
+#endif
 
 	if (live) {
 		atomicMax (&st->tp_call[0], __float_as_uint (fmaxf (pk0.x, pkf.x)));
@@ -461,6 +513,13 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 }  // namespace
 
 size_t mtr_seg_lds_bytes (void) { return LDS_BYTES; }
+
+#ifdef MTR_SEG_PROF
+extern "C" int mtr_debug_seg_prof (unsigned long long* out)
+{
+	return hipMemcpyFromSymbol (out, HIP_SYMBOL (g_seg_prof), 8 * sizeof (unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int mtr_launch_seg (bool ebu, const mtr_seg_args& a, uint32_t n_waves, void* stream)
 {
