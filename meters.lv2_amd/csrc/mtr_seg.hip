@@ -385,7 +385,15 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 #pragma unroll
 			for (int n = 0; n < R; ++n) if (n < lim) pk0 = v2f{fmaxf (pk0.x, fabsf (x[n].x)), fmaxf (pk0.y, fabsf (x[n].y))};
 		}
-		if (__builtin_expect (__ballot (__float_as_uint (ml) >= scl.cap || __float_as_uint (mr) >= scr.cap) != 0, 0)) rescale (ml, mr);
+		if (__builtin_expect (__ballot (__float_as_uint (ml) >= scl.cap || __float_as_uint (mr) >= scr.cap) != 0, 0)) {
+			// (the last chunk's accumulators of the step before are still waiting for their fold, which chunk 0 does: they
+			// belong to the old scale, so they are folded here, in front of the flush, and cleared)
+			fold (y1, 7);
+#pragma unroll
+			for (int p = 0; p < 3; ++p) y1[p] = m16::f4{0.f, 0.f, 0.f, 0.f};
+			rescale (ml, mr);
+			if (PROD) fetch.template operator()<U> (B0, 0);               // (fetched before the ring was rescaled: again)
+		}
 
 		// the stream, three steps ahead (the pointer stops with the segment: the last loads re-read its last line)
 #ifndef MTR_SEG_DBG_NOADV                                         /* (elimination runs, tools/seg_ab.sh: the same line over and over) */

@@ -208,10 +208,13 @@ def test_layout6_block_refinement_is_bit_identical(M):
         assert res[0, 0][2] == (0, 0)
 
 
-def test_layout6_is_the_default_for_true_peak(M):
+def test_layout7_is_the_default_for_true_peak(M):
+    # 7 = layout 6's kernel plus the lane = segment kernel for the calls that fit it (tests/test_gpu_seg.py)
     with M.Engine(1, 48000.0, M.METER_EBU | M.METER_TRUEPEAK) as e:
-        assert e.layout() == 6
+        assert e.layout() == 7
     with M.Engine(1, 48000.0, M.METER_TRUEPEAK) as e:
-        assert e.layout() == 6
+        assert e.layout() == 7
+    with M.Engine(1, 48000.0, M.METER_TRUEPEAK, tune_prune=1) as e:
+        assert e.layout() == 6                                   # pruning is layout 6's
     with M.Engine(1, 48000.0, M.METER_EBU) as e:
         assert e.layout() == 4

@@ -31,6 +31,7 @@ G = np.load(os.path.join(HERE, "golden", "golden_v1.npz"))
 
 DB_TOL = 1e-3
 CONTRACT_DB = 0.01
+MOVED_MAX = 2              # histogram points in a neighbouring 0.1 dB bin, at most, whatever the count: ONE bound for every check in this file
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +51,7 @@ def _check_ebu(got9, hist_got, want9, hist_want, cnt_want, frag_got=None, frag_w
     for h, w in zip(hist_got, hist_want):
         assert h.sum() == w.sum()
         moved = np.abs(h - w).sum() // 2
-        assert moved <= 2, moved             # a fragment power within ~1e-6 of a 0.1 dB bin edge; measured over this file: 0 or 1
+        assert moved <= MOVED_MAX, moved     # a fragment power within ~1e-6 of a 0.1 dB bin edge; measured over this file: 0 or 1
     # I, thresholds, LRA: the contract
     assert abs(got9[4] - want9[4]) <= CONTRACT_DB and abs(got9[5] - want9[5]) <= CONTRACT_DB
     # LRA edges are bin indices of the 0.1 dB S histogram: identical histogram -> identical edges, bit for bit;
@@ -157,13 +158,14 @@ def test_streaming_calls_equal_one_call(M, oracle, calls):
     assert np.allclose(one["frag"], many["frag"], rtol=2e-5)
     o = oracle.ebu(x[1], 48000.0, 1024, want_frag=True)
     assert np.allclose(many["frag"][1], o["frag_power"], rtol=2e-5)
-    assert np.abs(many["hist_M"][1] - o["hist_M"]).sum() <= 4
+    assert np.abs(many["hist_M"][1] - o["hist_M"]).sum() // 2 <= MOVED_MAX
 
 
-@pytest.mark.parametrize("run", [13, 39])
+@pytest.mark.parametrize("run", [38, 39])
 @pytest.mark.parametrize("segs", [1, 3, 7])
 def test_time_segments_and_tile_shapes(M, oracle, run, segs):
-    """Small batch: each stream split into warm-started time segments; both lane-run lengths."""
+    """Small batch: each stream split into warm-started time segments; 38-frame runs (layouts 6 and 7: the lane = segment kernel takes the
+    whole-fragment part of the call, forced by tune_segments) and 39-frame runs (layout 3)."""
     T = 48000 * 9
     x = np.stack([tri_noise(T, 77 + s, 0.5, period=96000) + np.float32(0.01 * s) for s in range(2)])
     r = _run_ebu_tp(M, x, tune_run=run, tune_segments=segs)
@@ -337,7 +339,7 @@ def test_full_size_properties(M, oracle):
         assert np.allclose(a[0][s, :4], o["out9"][:4], atol=DB_TOL), s
         assert abs(a[0][s, 4] - o["out9"][4]) <= CONTRACT_DB
         assert np.allclose(a[1][s], oracle.tp(host[s], fs, 8192), rtol=2e-6), s
-        assert np.abs(a[2][s] - o["hist_M"]).sum() <= 4
+        assert np.abs(a[2][s] - o["hist_M"]).sum() // 2 <= MOVED_MAX
     assert a[2].sum() == S * 100 and a[3].sum() == S * 20    # every stream: 100 M points, 20 S points
     buf.mul_(2.0)
     torch.cuda.synchronize()
@@ -388,7 +390,7 @@ def test_long_call_gate_spread_over_workgroups(M, oracle, meters):
         assert np.allclose(one[1][s], o["frag_power"], rtol=2e-5)
         assert np.allclose(one[0][s, :4], o["out9"][:4], atol=DB_TOL)
         assert abs(one[0][s, 4] - o["out9"][4]) <= 0.01 and abs(one[0][s, 6] - o["out9"][6]) <= 0.1001
-        assert np.abs(one[2][s] - o["hist_M"]).sum() <= 6 and np.abs(one[3][s] - o["hist_S"]).sum() <= 4
+        assert np.abs(one[2][s] - o["hist_M"]).sum() // 2 <= MOVED_MAX and np.abs(one[3][s] - o["hist_S"]).sum() // 2 <= MOVED_MAX
         assert (one[4][s].hist_M_count, one[4][s].hist_S_count) == tuple(o["counts"])
 
 
