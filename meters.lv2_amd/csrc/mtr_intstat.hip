@@ -6,16 +6,22 @@
 // k_sigdist replaces the loop of sdh_run (src/sigdistlv2.c:303-318): bin = rintf (180 + 150 x) into
 // 361 bins (this TU is built with -ffp-contract=off: the bin decision must not see an FMA),
 // peak bin (ties: the bin that reached the final maximum first, as the sequential `>` test gives),
-// sum and Welford mean / M2 in double (combined across lanes with Chan's formula: equal to the
-// sequential recurrence up to double rounding) — OVER THE BINNED SAMPLES.
+// the plain sum, and the reference's running mean / variance accumulators var_m, var_s in double.
 //
-// Stated deviation: the reference's running mean divides by `integration_time + s + 1` (:312-315), the index of
-// the sample among ALL samples, also those it skipped as out of range (|x| > 1.2, NaN).  While every sample is
-// binned — normalised audio — that is exactly Welford's recurrence and the two agree to double rounding.  Once
-// a sample has been skipped, the reference's var_m / var_s are no longer the mean and M2 of anything (later
-// samples weigh 1 / index instead of 1 / count); this kernel keeps the true moments of the binned samples
-// instead of mirroring that.  Bins, peak bin, sample count and the plain sum `avg` are not affected: they are
-// the reference's bit for bit with or without skipped samples (tests/test_gpu_intstat.py checks both regimes).
+// The reference's recurrence (:312-315) divides by `integration_time + s + 1`, the index of the sample among ALL samples,
+// also those it skipped as out of range (|x| > 1.2, NaN):
+//     m <- m + (v - m) / k,     S <- S + (v - m_new) (v - m_old) = S + (1 - 1/k) (v - m_old)^2 .
+//   * While every sample is binned — normalised audio — k is the count of binned samples and this is Welford's update:
+//     mean and M2 of the data, order-free.  Fast path: per-lane sums about a pivot over coalesced loads, merged with
+//     Chan's formula (equal to the sequential recurrence up to double rounding).
+//   * Once a sample has been skipped (in this call or an earlier one) the weights 1/k no longer match the count and
+//     var_m / var_s stop being moments of anything — but they are still what the reference reports, so they are
+//     reproduced: the update is AFFINE in m (m' = (1 - 1/k) m + v/k) and S gains a QUADRATIC in the incoming m, so a
+//     contiguous run of samples maps (m, S) -> (a m + b, S + A m^2 + B m + C); every lane builds that map for its own
+//     contiguous chunk of the call (the raw sample index gives k), and the 256 maps are applied in stream order.  This
+//     second pass re-reads the stream's call (L2 / HBM) and only runs for streams that have skipped a sample.
+// Bins, peak bin, sample count and the plain sum `avg` are the reference's bit for bit in both regimes
+// (tests/test_gpu_intstat.py checks both, var_m / var_s against the oracle at 1e-12 relative).
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -41,13 +47,14 @@ __global__ __launch_bounds__ (256) void k_sigdist (const float* audio, uint64_t 
 	// the data — without its division per sample (~25 fp64 instructions); mean and M2 of the slice follow
 	// at the end and the 256 slices are merged with Chan's pairwise formula (any partition gives the same
 	// moments up to double rounding).
-	uint32_t cnt = 0;
+	uint32_t cnt = 0, skipped = 0;
 	double K = 0, s1 = 0, s2 = 0, sum = 0;
 	const uint64_t count0 = (uint64_t) o->count;
+	const bool skipped_before = o->n_binned != o->count;       // (read before anybody writes the state back)
 	auto one = [&] (float val, uint32_t i) {
 		const float fb = rintf (180.f + val * 150.f);          // sigdistlv2.c:305
 		// `int bin = rintf (...)` then `if (bin < 0 || bin >= 361) continue`; NaN never passes
-		if (!(fb >= 0.f && fb < (float) MTR_DIST_BIN)) return;
+		if (!(fb >= 0.f && fb < (float) MTR_DIST_BIN)) { skipped = 1; return; }
 		const int bin = (int) fb;
 		atomicAdd (&bins[bin], 1);
 		atomicMax (&last[bin], i + 1u);
@@ -75,8 +82,39 @@ __global__ __launch_bounds__ (256) void k_sigdist (const float* audio, uint64_t 
 		mom[tid][2] = cnt ? s2 - s1 * s1 / nd : 0.0;
 		sums[tid] = sum;
 	}
-	__syncthreads ();
-	if (tid == 0) {
+	// has this stream ever skipped a sample?  (n_binned < count: in an earlier call)
+	const bool quirk = __syncthreads_or ((int) skipped) != 0 || skipped_before;
+	if (quirk) {
+		// the reference's recurrence with the raw sample index as divisor: lane t maps (m, S) over its contiguous chunk
+		const uint64_t chunk = (n_frames + 255) / 256;
+		const uint64_t i0 = (uint64_t) tid * chunk, i1 = min (i0 + chunk, n_frames);
+		double a = 1.0, b = 0.0, A = 0.0, B = 0.0, Cq = 0.0;
+		for (uint64_t i = i0; i < i1; ++i) {
+			const float val = src[i];
+			const float fb = rintf (180.f + val * 150.f);
+			if (!(fb >= 0.f && fb < (float) MTR_DIST_BIN)) continue;
+			const double v = (double) val, inv = 1.0 / (double) (count0 + i + 1), g = 1.0 - inv;
+			const double e = v - b, ga = g * a;                    // v - m_old = e - a m_in
+			A = fma (ga, a, A); B = fma (-2.0 * ga, e, B); Cq = fma (g * e, e, Cq);
+			a = ga; b = fma (g, b, inv * v);
+		}
+		mom[tid][0] = a; mom[tid][1] = b; mom[tid][2] = A;
+		sums[tid] = sum;
+		__shared__ double quad[256][2];
+		quad[tid][0] = B; quad[tid][1] = Cq;
+		__syncthreads ();
+		if (tid == 0) {
+			double m = o->var_m, S = o->var_s, Sum = o->avg;
+			for (int t = 0; t < 256; ++t) {
+				S += fma (mom[t][2] * m, m, fma (quad[t][0], m, quad[t][1]));
+				m = fma (mom[t][0], m, mom[t][1]);
+			}
+			for (int t = 0; t < 256; ++t) Sum += sums[t];
+			int64_t nb = 0;
+			for (int bq = 0; bq < MTR_DIST_BIN; ++bq) nb += bins[bq];
+			o->n_binned += nb; o->var_m = m; o->var_s = S; o->avg = Sum;
+		}
+	} else if (tid == 0) {
 		// fold the carried moments and the 256 slices in stream order (Chan et al.)
 		double N = (double) o->n_binned, Mu = o->var_m, M2 = o->var_s, Sum = o->avg;
 		for (int t = 0; t < 256; ++t) {
