@@ -8,29 +8,32 @@
 // stream p / 30, band p % 30 — so all 64 lanes of every wave work (a layout of 32 lanes per stream idles two in
 // every 32: 6 % of a kernel that issues VALU instructions 100 % of the time).  The 12-state recurrence of a band
 // is serial in time and, with pole radii up to 0.99991, not worth an exact time split (a 12x12 carry matrix per
-// band); with >= 4096 streams there are >= 122k independent lanes, which fills the chip.  A workgroup of 256 lanes
-// covers 8.5 streams: it stages a chunk of frames of the (up to) ten streams it touches through LDS with coalesced
-// loads, forming the mono mix (L+R)/2 and adding the anti-denormal toggle once per frame instead of once per
-// band; lanes then read their stream's row as an LDS broadcast.  Coefficients and states live in registers for the
+// band); with >= 4096 streams there are >= 122k independent lanes, which fills the chip.  A wave of 64 lanes
+// covers 2.1 streams: it stages chunks of frames of the (up to) four streams it touches through its own LDS buffers,
+// forming the mono mix (L+R)/2 and adding the anti-denormal toggle once per frame instead of once per
+// band; lanes then read their stream's row as an LDS broadcast.  Workgroup = one wave: no barrier anywhere.  Coefficients and states live in registers for the
 // whole call.  fp64 VALU bound: 25 fp64 + 4 fp32 instructions per (frame, band), 4 cycles each, and nothing else in
 // the loop — the kernel runs at that instruction floor (profiles/).
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
 
-#define BANK_ROWS  10     /* streams a block of 256 lanes can touch: ceil (255 / 30) + 1 */
-#define BANK_CHUNK 256    /* frames staged per stream per iteration */
-#define BANK_PITCH (BANK_CHUNK + 2)   /* doubles per row: rows two banks apart, so the <= 4 rows a wave reads never collide */
+#define BANK_ROWS  4      /* streams a wave of 64 lanes can touch: ceil (63 / 30) + 1 */
+#define BANK_CHUNK 128    /* frames staged per stream per iteration: two per lane */
+#define BANK_PITCH (BANK_CHUNK + 2)   /* doubles per row: rows four banks apart, so the <= 4 rows a wave reads never collide */
 
-__global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
+// One wave per workgroup, NO barrier: the wave stages the chunks of the (up to four) streams it touches through its own
+// two LDS buffers — chunk c + 1 is written, and chunk c + 2's loads are in flight, while chunk c is computed — so nothing
+// in the loop ever waits for another wave (round 2's four-wave workgroups spent 17 % of the SIMD time outside the
+// arithmetic: two barriers per 256 frames, on a kernel whose waves do not run in lock step).
+__global__ __launch_bounds__ (64) void k_bank (const mtr_bank_args a)
 {
-	__shared__ double mix[BANK_ROWS][BANK_PITCH];  // mono mix + the +-1e-12 anti-denormal toggle, as double
-	__shared__ int    par0[BANK_ROWS];
+	__shared__ double mix[2][BANK_ROWS][BANK_PITCH];    // mono mix + the +-1e-12 anti-denormal toggle, as double
 
-	const int tid = threadIdx.x;
-	const uint64_t pair0 = (uint64_t) blockIdx.x * 256;            // first (stream, band) pair of the block
-	const uint64_t pair  = pair0 + tid;
-	const uint32_t s0 = (uint32_t) (pair0 / MTR_NBANDS);           // first stream the block touches
+	const int lane = threadIdx.x;
+	const uint64_t pair0 = (uint64_t) blockIdx.x * 64;             // first (stream, band) pair of the wave
+	const uint64_t pair  = pair0 + lane;
+	const uint32_t s0 = (uint32_t) (pair0 / MTR_NBANDS);           // first stream the wave touches
 	const uint32_t s  = (uint32_t) (pair / MTR_NBANDS);
 	const int band = (int) (pair - (uint64_t) s * MTR_NBANDS);
 	const int row  = (int) (s - s0);
@@ -57,32 +60,55 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 		for (int i = 0; i < 12; ++i) z[i] = 0;
 	}
 	const float omega = a.omega;
-	if (tid < BANK_ROWS) { const uint32_t sg = s0 + tid; par0[tid] = sg < a.n_streams ? a.ac[sg] : 0; }
-	__syncthreads ();
-	const double* const my = &mix[row][0];
+	// the toggle parity each staged row starts the call with (all lanes keep all four: the staging is by frame, not by row)
+	int par0[BANK_ROWS];
+#pragma unroll
+	for (int g = 0; g < BANK_ROWS; ++g) par0[g] = (s0 + g < a.n_streams) ? a.ac_in[s0 + g] : 0;
+	const int my_par = live ? a.ac_in[s] : 0;
 
-	for (uint64_t base = 0; base < a.n_frames; base += BANK_CHUNK) {
-		const int nf = (int) min ((uint64_t) BANK_CHUNK, a.n_frames - base);
-		// stage: 256 lanes x up to 10 rows; row g of the block = stream s0 + g (a stream on a block boundary is
-		// staged by both blocks: 30 bands x 25 fp64 operations stand behind every 8 bytes read)
+	// lane t stages frames 2 t, 2 t + 1 of every row
+	float2 raw[BANK_ROWS][2];
+	auto fetch = [&] (uint64_t base) {
 #pragma unroll
 		for (int g = 0; g < BANK_ROWS; ++g) {
 			const uint32_t sg = s0 + g;
-			float m = 0.f;
-			if (sg < a.n_streams && tid < nf) {
-				if (a.n_channels == 2) {
-					const float2 f = reinterpret_cast<const float2*> (a.audio)[(size_t) sg * a.stride + base + tid];
-					m = (f.x + f.y) / 2.0f;          // spectrumlv2.c:216
-				} else {
-					m = a.audio[(size_t) sg * a.stride + base + tid];
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				const uint64_t f = base + 2 * lane + k;
+				float2 v = make_float2 (0.f, 0.f);
+				if (sg < a.n_streams && f < a.n_frames) {
+					if (a.n_channels == 2) v = reinterpret_cast<const float2*> (a.audio)[(size_t) sg * a.stride + f];
+					else                   v.x = a.audio[(size_t) sg * a.stride + f];
 				}
+				raw[g][k] = v;
 			}
-			// bandpass_process toggles `ac` before use: sample i of the call gets +1e-12 when ac0 ^ 1 ^ (i & 1)
-			const int pz = par0[g] ^ 1 ^ (int) ((base + tid) & 1);
-			mix[g][tid] = (double) m + (pz ? 1e-12 : -1e-12);       // spectr.c:81-82
 		}
-		__syncthreads ();
+	};
+	auto stage = [&] (int buf, uint64_t base) {
+#pragma unroll
+		for (int g = 0; g < BANK_ROWS; ++g)
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				const float m = a.n_channels == 2 ? (raw[g][k].x + raw[g][k].y) / 2.0f : raw[g][k].x;   // spectrumlv2.c:216
+				// bandpass_process toggles `ac` before use: sample i of the call gets +1e-12 when ac0 ^ 1 ^ (i & 1)
+				const int pz = par0[g] ^ 1 ^ (int) ((base + k) & 1);                                       // (2 lane is even)
+				mix[buf][g][2 * lane + k] = (double) m + (pz ? 1e-12 : -1e-12);                               // spectr.c:81-82
+			}
+	};
 
+	fetch (0);
+	stage (0, 0);
+	fetch (BANK_CHUNK);
+	int buf = 0;
+	for (uint64_t base = 0; base < a.n_frames; base += BANK_CHUNK, buf ^= 1) {
+		const int nf = (int) min ((uint64_t) BANK_CHUNK, a.n_frames - base);
+		// the next chunk into the other buffer (its previous readers are behind us in this wave's own instruction stream),
+		// the one after it into the registers: both land under this chunk's arithmetic
+		if (base + BANK_CHUNK < a.n_frames) {
+			stage (buf ^ 1, base + BANK_CHUNK);
+			fetch (base + 2 * BANK_CHUNK);
+		}
+		const double* const my = &mix[buf][row][0];
 		for (int n = 0; n < nf; ++n) {
 			// six TDF-II sections (spectr.c:68-76).  Section 0 carries the normalisation g: numerator
 			// g (1, 2, 1); sections 1-5 have (1, +-2, 1): b0 in = b2 in = in and b1 in = +-2 in are exact, so
@@ -108,7 +134,6 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 			// `val > mx ? val : mx` (spectrumlv2.c:222) as one v_max_f32: a NaN val loses either way, mx is never NaN
 			mx = __builtin_fmaxf (mx, val);
 		}
-		__syncthreads ();
 	}
 
 	if (live) {
@@ -122,15 +147,16 @@ __global__ __launch_bounds__ (256) void k_bank (const mtr_bank_args a)
 		}
 		a.val[(size_t) s * MTR_NBANDS + band] = val + 1e-20f;
 		a.mx[(size_t) s * MTR_NBANDS + band]  = mx;
-		if (band == 0) a.ac[s] = par0[row] ^ (int) (a.n_frames & 1);
+		// the parity of the next call goes to the OTHER buffer: a wave that starts late must not see this call's update
+		if (band == 0) a.ac_out[s] = my_par ^ (int) (a.n_frames & 1);
 	}
 }
 
 int mtr_launch_bank (const mtr_bank_args& a, void* stream)
 {
 	const uint64_t pairs = (uint64_t) a.n_streams * MTR_NBANDS;
-	const uint32_t nb = (uint32_t) ((pairs + 255) / 256);
-	hipLaunchKernelGGL (k_bank, dim3 (nb), dim3 (256), 0, (hipStream_t) stream, a);
+	const uint32_t nb = (uint32_t) ((pairs + 63) / 64);
+	hipLaunchKernelGGL (k_bank, dim3 (nb), dim3 (64), 0, (hipStream_t) stream, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 

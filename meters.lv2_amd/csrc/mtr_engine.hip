@@ -118,7 +118,8 @@ struct mtr_engine {
 	hipEvent_t       xs_event = nullptr;     // orders a new stream behind the previous one
 	DevBuf<double>   bank_coef, bank_z;
 	DevBuf<float>    bank_val, bank_max;
-	DevBuf<int32_t>  bank_ac;
+	DevBuf<int32_t>  bank_ac[2];     // ping-pong: k_bank reads one, writes the other
+	int              bank_ac_cur = 0;
 	DevBuf<mtr_bitstats_state> bim;
 	DevBuf<mtr_sigdist_state>  sdh;
 	DevBuf<mtr_dr14_state>     dr_state;
@@ -239,6 +240,7 @@ static int upload_consts (mtr_engine* e)
 
 static int state_init (mtr_engine* e, int what, hipStream_t st)
 {
+	e->queued = true;                // (work on last_stream: a caller that moves to another stream must be ordered behind it)
 	if (mtr_launch_state_init (e->state.p, e->hist.p, e->cfg.n_streams, what, st)) return fail (MTR_ERR_HIP, "k_state_init");
 	return MTR_OK;
 }
@@ -361,7 +363,7 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 		}
 		if (e->bank_coef.reserve (c.size ()) || e->bank_z.reserve ((size_t) S * MTR_NBANDS * 12)
 		    || e->bank_val.reserve ((size_t) S * MTR_NBANDS) || e->bank_max.reserve ((size_t) S * MTR_NBANDS)
-		    || e->bank_ac.reserve (S))
+		    || e->bank_ac[0].reserve (S) || e->bank_ac[1].reserve (S))
 			rc = fail (MTR_ERR_NOMEM, "hipMalloc bank state");
 		else if (hipMemcpy (e->bank_coef.p, c.data (), c.size () * sizeof (double), hipMemcpyHostToDevice) != hipSuccess)
 			rc = fail (MTR_ERR_HIP, "hipMemcpy bank_coef");
@@ -386,7 +388,7 @@ void mtr_engine_destroy (mtr_engine* e)
 	e->pin_in.release (); e->pin_state.release (); e->pin_bank.release ();
 	if (e->own_stream) (void) hipStreamDestroy (e->own_stream);
 	if (e->xs_event) (void) hipEventDestroy (e->xs_event);
-	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac.release ();
+	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac[0].release (); e->bank_ac[1].release ();
 	e->fir_g.release (); e->m16_a.release ();
 	e->bim.release (); e->sdh.release (); e->prune_cnt.release ();
 	e->dr_state.release (); e->dr_hist.release (); e->dr_sum.release (); e->dr_peak.release ();
@@ -409,7 +411,9 @@ int mtr_engine_reset (mtr_engine* e)
 		HIPCHK (hipMemsetAsync (e->bank_z.p, 0, e->bank_z.n * sizeof (double), st));
 		HIPCHK (hipMemsetAsync (e->bank_val.p, 0, e->bank_val.n * sizeof (float), st));
 		HIPCHK (hipMemsetAsync (e->bank_max.p, 0, e->bank_max.n * sizeof (float), st));
-		HIPCHK (hipMemsetAsync (e->bank_ac.p, 0, e->bank_ac.n * sizeof (int32_t), st));
+		HIPCHK (hipMemsetAsync (e->bank_ac[0].p, 0, e->bank_ac[0].n * sizeof (int32_t), st));
+		HIPCHK (hipMemsetAsync (e->bank_ac[1].p, 0, e->bank_ac[1].n * sizeof (int32_t), st));
+		e->bank_ac_cur = 0;
 	}
 	e->frcnt = e->fragm;
 	e->integr = false;
@@ -588,6 +592,7 @@ int mtr_engine_spectr_reset_peak (mtr_engine* e)
 	e->snap_valid = false;
 	HIPCHK (hipSetDevice (e->cfg.device));
 	HIPCHK (hipMemsetAsync (e->bank_max.p, 0, e->bank_max.n * sizeof (float), e->last_stream));
+	e->queued = true;
 	return MTR_OK;
 }
 
@@ -831,9 +836,10 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (bank) {
 		mtr_bank_args ba;
 		ba.audio = d_audio; ba.stride = stride; ba.n_frames = n_frames;
-		ba.coef = e->bank_coef.p; ba.z = e->bank_z.p; ba.val = e->bank_val.p; ba.mx = e->bank_max.p; ba.ac = e->bank_ac.p;
+		ba.coef = e->bank_coef.p; ba.z = e->bank_z.p; ba.val = e->bank_val.p; ba.mx = e->bank_max.p; ba.ac_in = e->bank_ac[e->bank_ac_cur].p; ba.ac_out = e->bank_ac[e->bank_ac_cur ^ 1].p;
 		ba.n_streams = S; ba.n_channels = e->cfg.n_channels; ba.omega = e->omega;
 		if (mtr_launch_bank (ba, st)) return fail (MTR_ERR_HIP, "k_bank launch");
+		e->bank_ac_cur ^= 1;
 	}
 	// (the integer tables are int32, as the reference's, which stops counting at 2^31 - 1 samples; the kernels index
 	// a call's samples with 32 bits: checked on entry)

@@ -97,7 +97,8 @@ struct mtr_bank_args {
 	double*         z;            /* [S][30][12] section states */
 	float*          val;          /* [S][30] */
 	float*          mx;           /* [S][30] */
-	int32_t*        ac;           /* [S] dither toggle parity (shared by the 30 bands of a stream) */
+	const int32_t*  ac_in;        /* [S] dither toggle parity at the start of the call (shared by the 30 bands of a stream) */
+	int32_t*        ac_out;       /* [S] ... and after it: ANOTHER buffer (a workgroup that starts late must still read the old one) */
 	uint32_t        n_streams, n_channels;
 	float           omega;
 };
