@@ -15,10 +15,10 @@ peak / max-loudness values (max), done once per step by mtr_engine_reduce() — 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  `value` counts channel-samples/s (2 per stereo frame), whole job.
-`roofline` prices the dominant kernel (k_kwtp16, mtr_fused4.hip: K-weighting + the 4x interpolator on the
-matrix pipe at f32 grade) at 8 algorithmic bytes per stereo frame (one read of the input)
-against the 8 TB/s HBM peak, with the kernel's duration measured by HIP events on the launching stream
-inside the timed steps.  `extra.configs` carries every BASELINE config at its stated size, `extra.lv2_run_latency`
+`roofline` prices the dominant kernel (k_seg, mtr_seg.hip: K-weighting as the reference's recurrence with lane = time
+segment + the 4x interpolator on the matrix pipe at f32 grade; the layout every call of this shape takes by default) at
+8 algorithmic bytes per stereo frame (one read of the input) against the 8 TB/s HBM peak, with the
+kernel's duration measured by HIP events on the launching stream inside the timed steps.  `extra.configs` carries every BASELINE config at its stated size, `extra.lv2_run_latency`
 the per-block cost of the LV2 plugins.  `cpu_baseline` times the reference's
 own DSP objects (oracle/_ref, kind "reference") — or the repo's restatement (kind "port") where
 that build is absent — on a bounded sample of the same buffers on the host cores.
@@ -84,7 +84,7 @@ def kernel_sha():
     """Hash of the sources of the dominant kernel: the committed PMC traffic figure is valid for exactly this code."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("mtr_fused4.hip", "mtr_mfma16_fir.h", "mtr_wave.h", "mtr_kw_steps.h"):
+    for f in ("mtr_seg.hip", "mtr_mfma16_fir.h", "Makefile"):
         h.update(open(os.path.join(ROOT, "meters.lv2_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -92,9 +92,9 @@ def kernel_sha():
 def committed_traffic(meters, S, T, layout):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md):
     the counters cannot be read from inside this process, so the figure is reported only for the very workload AND the
-    very kernel sources it was measured on (profiles/r02_traffic.json carries their hash); otherwise null."""
+    very kernel sources it was measured on (profiles/r03_traffic.json carries their hash); otherwise null."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
         w = tj["workload"]
         if (meters, S, T, layout) == (w["meters"], w["streams_per_gpu"], w["frames_per_stream"], w["layout"]) \
                 and tj["kernel_sha16"] == kernel_sha():
@@ -153,8 +153,9 @@ def main():
                                                            "bitstats", "sigdist", "tpb", "dr14", "kmeter"])
     ap.add_argument("--run", type=int, default=0, help="frames per lane run (0 = engine default)")
     ap.add_argument("--segments", type=int, default=0)
-    ap.add_argument("--layout", type=int, default=0, help="0 auto (6 with true peak, 4 without), 1 wave per segment, 2/3 exact-f32 VALU interpolator, "
-                                                          "4 K-weighting only, 5 matrix pipe with f16 taps (round 1), 6 matrix pipe at f32 grade")
+    ap.add_argument("--layout", type=int, default=0, help="0 auto (7 with true peak, 4 without), 3 exact-f32 VALU interpolator, 4 K-weighting only, "
+                                                          "6 matrix pipe at f32 grade with a wave per (stream, segment), 7 = 6 + lane = segment for the calls that fit")
+    ap.add_argument("--signal", type=int, default=1, help="synthetic signal: 1 programme-like (default), 0 stationary noise, 2 noise under a monotonically rising level")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.lv2_run_latency (N = 1 only anyway)")
     ap.add_argument("--fir", type=int, default=0, help="0 auto (mirror-symmetric form), 1 dense 3x48 taps")
     ap.add_argument("--prune", type=int, default=0, help="1 = exact true-peak pruning (identical result, data-dependent speed)")
@@ -210,7 +211,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     # synthetic programme-like signal, a different LCG seed per stream across the whole job
     first, _ = mdist.shard(S * world, world, rank)
-    M.synth_fill_device(buf.data_ptr(), S, T, T, 777 + first, fs, 1, stream)
+    M.synth_fill_device(buf.data_ptr(), S, T, T, 777 + first, fs, args.signal, stream)
     agg_hist = torch.zeros(2 * 751, dtype=torch.int32, device=dev)
     agg_max = torch.zeros(4, dtype=torch.float32, device=dev)
 
@@ -300,21 +301,30 @@ def main():
                                "kernel": kname, "kernel_ms": k_ms, "gate_ms": tq["ms_gate"] / tq["calls"],
                                "algorithmic_bytes_per_launch": S * T * BYTES_PER_FRAME}
             if layout in (6, 7):
-                # what binds: issue slots of the SIMDs.  Per stereo frame the kernel issues 18 x 2 / 256 MFMAs
-                # (16x16x32 f16, 16 cycles of the matrix pipe each) and ~37 VALU instructions (~23 without the K-filter);
-                # packed-f32 VALU work and MFMAs do not overlap on a SIMD (tools/coissue.hip), so the two add up.
-                mfma_flop = 2.0 * 16 * 16 * 32 * (36.0 / 256.0) * S * T / (k_ms * 1e-3)
+                seg = layout == 7 and eng.seg_stats()[0] > 0
+                # What binds: issue cycles of the SIMDs under the socket's power cap, not HBM.  Per 16 frames of 64 lanes (one step
+                # of a k_seg wave, 1024 stereo frames) the matrix pipe is busy 144 MFMAs x 16 cycles = 2304 cycles (three f16
+                # partial products for f32 grade); two scalar VALU instructions issue for free in an MFMA's shadow (tools/coissue.hip),
+                # the step's other ~210 scalar-equivalents of VALU work (K-weighting recurrence: 11 packed f32 per frame) do not:
+                # ~2.2 cycles each.  profiles/r03_kseg_step_cycles.txt has the measured step (4.3 k cycles) and the clock the power
+                # cap allows under this kernel (1.63 GHz of 2.4: profiles/r03_kseg_clock.txt) — both are properties of the committed
+                # profile, not of this run; this run contributes kernel_ms.
+                steps = S * T / 1024.0
+                n_simd = 1024.0
+                mfma_cycles = steps * 144 * 16 / n_simd
+                floor_cycles = steps * (144 * 16 + (210 * 2.2 if meters & M.METER_EBU else 0)) / n_simd
                 out["roofline"]["binding_roofline"] = {
-                    "bound": "SIMD issue: f16 MFMA (3 partial products) + packed-f32 VALU, not overlapping",
-                    "mfma_achieved_tflops": mfma_flop / 1e12, "mfma_peak_tflops": 2500.0, "mfma_frac": mfma_flop / 2.5e15}
-                out["roofline"]["note"] = ("interpolator on the matrix pipe at f32 grade (samples and taps as two f16 halves, three "
-                                           "partial products, f32 accumulation): same 2e-6 parity bound as the exact-f32 VALU path")
+                    "bound": "SIMD issue cycles under the power cap: f16 MFMA (3 partial products) + the VALU work that does not fit the MFMA shadows",
+                    "mfma_pipe_cycles_per_simd": mfma_cycles, "issue_floor_cycles_per_simd": floor_cycles,
+                    "kernel_ms_at_floor_and_2p4_ghz": floor_cycles / 2.4e6, "kernel_ms_at_floor_and_profiled_clock_1p63_ghz": floor_cycles / 1.63e6,
+                    "frac_of_floor_at_profiled_clock": (floor_cycles / 1.63e6) / k_ms,
+                    "mfma_achieved_tflops": 2.0 * 16 * 16 * 32 * 144 * steps / (k_ms * 1e-3) / 1e12, "mfma_peak_tflops": 2500.0}
+                out["roofline"]["note"] = (("lane = time segment (k_seg): " if seg else "wave per (stream, segment) (k_kwtp16): ") +
+                                           "K-weighting = the reference's recurrence in packed f32; interpolator on the matrix pipe at f32 grade "
+                                           "(samples and taps as two f16 halves, three partial products, f32 accumulation): same 2e-6 parity "
+                                           "bound as the exact-f32 VALU path")
                 out["dtype"] = "f32 (K-filter: packed f32 VALU; interpolator: f16x2-split samples x f16x2-split taps on MFMA, f32 accumulate)"
-            elif layout == 5:
-                out["roofline"]["note"] = ("layout 5 (round 1): matrix pipe with single-f16 taps, peaks within 0.0056 dB of the f32 "
-                                           "interpolator — narrower than the reference, kept for comparison only")
-                out["dtype"] = "f32 K-filter; f16x2-split samples, f16 taps, f32 accumulation in the interpolator"
-            elif layout in (1, 2, 3) and meters & M.METER_TRUEPEAK:
+            elif layout == 3 and meters & M.METER_TRUEPEAK:
                 valu_ops = 143.0 * S * T / (k_ms * 1e-3) * 2 * 2        # flop/s: 2 lanes x FMA
                 out["roofline"]["binding_roofline"] = {"bound": "fp32 VALU (v_pk_fma_f32)", "achieved_tflops": valu_ops / 1e12,
                                                        "peak_tflops": 157.3, "frac": valu_ops / 157.3e12}
@@ -361,24 +371,69 @@ def main():
                     c = max(q["calls"], 1)
                     keep = {"tp": x.truepeak() if emeters & M.METER_TRUEPEAK else None,
                             "o9": x.out9() if emeters & M.METER_EBU else None, "prune": x.prune_stats(), "refine": x.refine_stats(),
-                            "layout": x.layout()}
+                            "layout": x.layout(),
+                            "kernel": "k_seg" if x.seg_stats()[0] else {7: "k_kwtp16", 6: "k_kwtp16", 4: "k_kw", 3: "k_fused2"}.get(x.layout(), "?")}
                 return q["ms_fused"] / c, q["ms_gate"] / c, q["ms_bank"] / c, wall, keep
 
             def frac(eS, eT, ms):
                 return eS * eT * BYTES_PER_FRAME / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
-            # Next to — never instead of — `value`: exact peak pruning (bit-identical peaks, data-dependent speed) and the
-            # exact-f32 VALU interpolator of round 1 (layout 3), whose peaks the matrix-pipe path must reproduce.
-            f, g, _, _, k = timed(S, T, meters, tune_prune=1)
-            extra["exact_pruning"] = {"kernel_ms": f, "frac": frac(S, T, f), "tiles_skipped_frac": k["prune"][1] / max(k["prune"][0], 1),
-                                      "peaks_identical_to_dense": bool(np.array_equal(k["tp"], peaks)),
-                                      "note": "optional (tune_prune=1); not part of `value`"}
-            f, g, _, _, k = timed(S, T, meters, tune_prune=2)
-            extra["exact_pruning_block_refinement"] = {
-                "kernel_ms": f, "frac": frac(S, T, f), "tiles_skipped_frac": k["prune"][1] / max(k["prune"][0], 1),
-                "blocks_completed_frac": k["refine"][1] / max(k["refine"][0], 1),
-                "peaks_identical_to_dense": bool(np.array_equal(k["tp"], peaks)),
-                "note": "optional (tune_prune=2): blocks screened with the first f16 product, completed only near the peak; not part of `value`"}
+            # Next to — never instead of — `value`: the wave-per-segment kernel this layout falls back to (k_kwtp16, round 2's
+            # default), its exact peak pruning (bit-identical peaks, data-dependent speed), and the exact-f32 VALU interpolator
+            # of round 1 (layout 3), whose peaks the matrix-pipe paths must reproduce.
+            f, g, _, _, k6 = timed(S, T, meters, tune_layout=6)
+            rel = np.abs(k6["tp"].astype(np.float64) - peaks) / np.maximum(peaks.astype(np.float64), 1e-30)
+            extra["wave_per_segment_k_kwtp16"] = {"kernel": "k_kwtp16", "kernel_ms": f, "frac": frac(S, T, f),
+                                                  "max_rel_dev_of_default_peaks": float(rel.max()),
+                                                  "max_abs_dev_integrated_lufs": float(np.abs(k6["o9"][:, 4].astype(np.float64) - o9[:, 4]).max()),
+                                                  "note": "tune_layout=6: round 2's default; serves the calls k_seg does not fit"}
+            # exact pruning with evidence — on the bench programme, on stationary noise without an envelope and
+            # on a level that rises monotonically (every block beats everything before it: nothing can be pruned)
+            pr = {}
+            tmp = torch.empty_like(buf)
+            for name, kind in (("programme (the bench signal)", 1), ("stationary noise, no envelope", 0), ("monotonically rising level (worst case)", 2)):
+                src = buf
+                if kind != 1:
+                    M.synth_fill_device(tmp.data_ptr(), S, T, T, 777 + first, fs, kind, stream)
+                    src = tmp
+                row = {}
+                for lvl in (0, 1, 2):
+                    with M.Engine(S, fs, meters, device=local, tune_layout=6, tune_prune=lvl) as x:
+                        x.integr_start()
+                        x.process_device(src.data_ptr(), T, T, stream)
+                        torch.cuda.synchronize()
+                        first_skip = x.prune_stats()[1]
+                        first_ref = x.refine_stats()
+                        x.timing_enable(True)
+                        for _ in range(3):
+                            # every timed call starts from a reset engine: a second call on the same buffer would begin with
+                            # the first one's (loud) last frames as history, and on the rising signal that alone prunes 83 %
+                            x.reset()
+                            x.integr_start()
+                            x.process_device(src.data_ptr(), T, T, stream)
+                        torch.cuda.synchronize()
+                        q = x.timing_query()
+                        ms = q["ms_fused"] / max(q["calls"], 1)
+                        tpk = x.truepeak()
+                        if lvl == 0:
+                            dense_tp, dense_ms = tpk, ms
+                            row["dense_kernel_ms"] = ms
+                        else:
+                            c, kk = x.prune_stats()
+                            c, kk = c - c // 4, kk - first_skip     # (the three timed calls)
+                            e = {"kernel_ms": ms, "frac": frac(S, T, ms), "vs_dense": ms / dense_ms, "tiles_skipped_frac": kk / max(c, 1),
+                                 "peaks_identical_to_dense": bool(np.array_equal(tpk, dense_tp))}
+                            if lvl == 2:
+                                a_, b_ = x.refine_stats()
+                                e["blocks_completed_frac"] = (b_ - first_ref[1]) / max(a_ - first_ref[0], 1)
+                            row["tune_prune=%d" % lvl] = e
+                pr[name] = row
+            del tmp
+            pr["note"] = ("k_kwtp16 (layout 6) only; exact branch and bound on L1 * max|x| per tile (1) and per 256-frame block after the first "
+                          "f16 product (2): identical peaks, data-dependent speed — never part of `value`.  The worst case costs a few per "
+                          "cent over dense; with k_seg as the default the pruning stays an option of layout 6 (it is a per-tile decision, "
+                          "k_seg has no tiles) and is not the engine default.")
+            extra["exact_pruning"] = pr
             f, g, _, _, k = timed(S, T, meters, tune_layout=3)
             rel = np.abs(k["tp"].astype(np.float64) - peaks) / np.maximum(peaks.astype(np.float64), 1e-30)
             extra["f32_valu_interpolator"] = {"kernel": "k_fused2", "kernel_ms": f, "frac": frac(S, T, f),
@@ -391,19 +446,30 @@ def main():
             f, g, _, w, _ = timed(1, c1, M.METER_EBU, steps=5)
             cfgs["1: EBU R128, 1 stream x 3600 s"] = {"kernel": "k_kw", "kernel_ms": f, "gate_ms": g, "wall_ms": w, "frac": frac(1, c1, f),
                                                       "whole_step_frac": frac(1, c1, w), "bound": "hbm"}
-            f, g, _, w, _ = timed(1, c1, meters, steps=5)
-            cfgs["1 + true peak: 1 stream x 3600 s"] = {"kernel": "k_kwtp16", "kernel_ms": f, "gate_ms": g, "wall_ms": w, "frac": frac(1, c1, f),
+            f, g, _, w, k = timed(1, c1, meters, steps=5)
+            cfgs["1 + true peak: 1 stream x 3600 s"] = {"kernel": k["kernel"], "kernel_ms": f, "gate_ms": g, "wall_ms": w, "frac": frac(1, c1, f),
                                                         "whole_step_frac": frac(1, c1, w), "bound": "SIMD issue (MFMA + VALU)"}
-            f, _, _, w, _ = timed(1024, 60 * 48000, M.METER_TRUEPEAK)
-            cfgs["2: 4x true peak, 1024 streams x 60 s"] = {"kernel": "k_kwtp16", "kernel_ms": f, "wall_ms": w, "frac": frac(1024, 60 * 48000, f),
-                                                          "bound": "SIMD issue (MFMA + VALU)"}
+            f, _, _, w, k = timed(1024, 60 * 48000, M.METER_TRUEPEAK)
+            cfgs["2: 4x true peak, 1024 streams x 60 s"] = {"kernel": k["kernel"], "kernel_ms": f, "wall_ms": w, "frac": frac(1024, 60 * 48000, f),
+                                                          "bound": "SIMD issue (MFMA) under the power cap"}
             _, _, bk, w, _ = timed(4096, T, M.METER_SPECTR30, steps=2)
             cfgs["3: 30-band bank, 4096 streams x 10 s"] = {"kernel": "k_bank", "kernel_ms": bk, "wall_ms": w, "frac": frac(4096, T, bk),
                                                            "bound": "fp64 VALU (ceiling 4.2-5.0 % of HBM peak, SURVEY.md 8d)"}
-            f, g, bk, w, _ = timed(S, T, meters | M.METER_SPECTR30, steps=2)
+            f, g, bk, w, k = timed(S, T, meters | M.METER_SPECTR30, steps=2)
             cfgs["4: EBU + true peak + bank, 8192 streams x 10 s (one of 8 shards)"] = {
-                "kernel_ms": {"k_kwtp16": f, "k_gate": g, "k_bank": bk}, "wall_ms": w, "frac": frac(S, T, w),
-                "bound": "fp64 VALU (k_bank) + SIMD issue (k_kwtp16); the bank's second read of the audio is %.1f %% of the step" % (100 * (S * T * 8 / 5.0e12 * 1e3) / w)}
+                "kernel_ms": {k["kernel"]: f, "k_gate": g, "k_bank": bk}, "wall_ms": w, "frac": frac(S, T, w),
+                "bound": "fp64 VALU (k_bank) + SIMD issue (%s); the bank's second read of the audio is %.1f %% of the step" % (k["kernel"], 100 * (S * T * 8 / 5.0e12 * 1e3) / w)}
+            # the other meter sets at the headline shape, under the same clock as everything else in this line
+            f, g, _, w, k = timed(S, T, M.METER_EBU, steps=5)
+            cfgs["EBU R128 only, 8192 streams x 10 s"] = {"kernel": k["kernel"], "kernel_ms": f, "gate_ms": g, "wall_ms": w, "frac": frac(S, T, f), "bound": "hbm"}
+            f, _, _, w, k = timed(S, T, M.METER_TRUEPEAK, steps=5)
+            cfgs["true peak only, 8192 streams x 10 s"] = {"kernel": k["kernel"], "kernel_ms": f, "wall_ms": w, "frac": frac(S, T, f),
+                                                           "bound": "SIMD issue (MFMA) under the power cap"}
+            _, _, bk, w, _ = timed(S, T, M.METER_TPBALLIST, steps=2)
+            cfgs["true-peak ballistics (TruePeakdsp::process), 8192 streams x 10 s"] = {
+                "kernel": "k_tpb", "kernel_ms": bk, "wall_ms": w, "frac": frac(S, T, bk),
+                "bound": "latency of the serial attack / release chain: one lane per (stream, channel) walks 4 x 480 000 dependent steps; 16 384 chains "
+                         "occupy a quarter of the chip's lanes (DESIGN.md 3.5)"}
             extra["configs"] = cfgs
             try:
                 from _lv2host import Host

@@ -247,7 +247,8 @@ int  mtr_fir_table (float* out120);
 int  mtr_band_coef (double rate, uint32_t band, double* out36);
 
 /* Fill device memory with the repo's seeded synthetic programme signal:
- * stream s = LCG(seed + s) noise under a slow envelope plus a tone. Used by bench.py so the
+ * stream s = LCG(seed + s) noise under a slow envelope plus a tone (kind 1); kind 0 = the plain LCG noise, kind 2 = that
+ * noise under a level rising monotonically by 48 dB (the worst case of exact peak pruning). Used by bench.py so the
  * timed region starts with inputs resident in HBM. */
 int  mtr_synth_fill_device (float* d_audio, uint32_t n_streams, uint64_t n_frames,
                             uint64_t stream_stride_frames, uint32_t seed, float sample_rate,

@@ -162,6 +162,7 @@ int mtr_launch_bank (const mtr_bank_args& a, void* stream)
 
 // ---- synthetic programme signal ------------------------------------------------------------------
 // kind 0: LCG noise (two draws per frame, L then R), u = ((s >> 8) - 2^23) / 2^23
+// kind 2: kind 0 under a monotonically rising level (2^-8 .. 1): the pruning-hostile case of bench.py
 // kind 1: programme-like: env(t) * (0.5 u + 0.5 sin(2 pi f t)), f_L = 440, f_R = 3000,
 //         env = 0.05 + 0.45 (0.5 + 0.5 sin(2 pi 0.2 t)); stream s uses seed + s.
 // The LCG is jumped to each thread's position with the closed form s_n = A^n s_0 + C (A^n - 1)/(A - 1),
@@ -208,6 +209,11 @@ __global__ void k_synth (float* audio, uint32_t n_streams, uint64_t n_frames, ui
 			const float pr = (float) ((f * 3000ull) % (uint64_t) fs) / fs;
 			ul = env * (0.5f * ul + 0.5f * __sinf (6.2831853f * pl));
 			ur = env * (0.5f * ur + 0.5f * __sinf (6.2831853f * pr));
+		} else if (kind == 2) {
+			// noise under a level that rises monotonically by 48 dB over the stream: every block's maximum beats everything
+			// before it — the worst case of exact peak pruning (nothing can be skipped, every screened block is completed)
+			const float env = exp2f (-8.0f + 8.0f * (float) f / (float) n_frames);
+			ul *= env; ur *= env;
 		}
 		dst[f] = make_float2 (ul, ur);
 	}
