@@ -176,7 +176,10 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 #else
 	auto load = [&]<int B> () __attribute__ ((always_inline)) {
 #pragma unroll
-		for (int i = 0; i < R / 2; ++i) { const float4 v = lp[i]; xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w}; }
+		for (int i = 0; i < R / 2; ++i) {
+			const float4 v = lp[i];      // (plain loads: the eight 16-byte reads of a lane's line merge in the L1 — as nt loads they go to the L2 one by one: 17.4 ms)
+			xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w};
+		}
 	};
 #endif
 	load.template operator()<0> (); lp += R / 2;

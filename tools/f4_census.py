@@ -30,20 +30,22 @@ HOT = collections.OrderedDict([
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    dump = subprocess.run([sys.executable, os.path.join(here, "isa_blocks.py"), sys.argv[1], "k_kwtp16ILi38ELb1ELb1E"],
+    dump = subprocess.run([sys.executable, os.path.join(here, "isa_blocks.py"), sys.argv[1], "k_kwtp16ILi38ELb1E"],
                           capture_output=True, text=True, check=True).stdout
     keys = "mfma vpk vdpp valu vlane salu smem vmem lds wait br".split()
     blocks = {}
     for l in dump.split("\n"):
         m = re.match(r"^(\S+)\s+(\d+) \|" + r"\s+(\d+)" * 11, l)
         if m: blocks[m.group(1)] = dict(zip(keys, map(int, m.groups()[2:])))
+    # (the labels in HOT carry the function index of the build the table was made with: .LBB2_*; follow the current one)
+    pref = next((b.split("_")[0] for b in blocks if b.startswith(".LBB")), ".LBB2")
     tot = collections.Counter()
     print("| phase | MFMA | packed f32 | DPP | other VALU | readlane | SALU | SMEM | VMEM | LDS | waitcnt / nop | branch |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name, lst in HOT.items():
         c = collections.Counter()
         for b, n in lst:
-            for k, v in blocks[b].items(): c[k] += v * n
+            for k, v in blocks[b.replace(".LBB2", pref)].items(): c[k] += v * n
         tot.update(c)
         print("| " + name + " | " + " | ".join(str(c[k]) for k in keys) + " |")
     print("| **sum** | " + " | ".join(str(tot[k]) for k in keys) + " |")
