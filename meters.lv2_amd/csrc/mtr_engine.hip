@@ -706,6 +706,9 @@ static int build_plan (mtr_engine* e, uint64_t N, uint32_t body_tiles, hipStream
 	memcpy (ps.pin.p + ts.size () + sg.size (), ft.data (), ft.size () * 4);
 	memcpy (ps.pin.p + ts.size () + sg.size () + ft.size (), tseg, 8);
 	HIPCHK (hipMemcpyAsync (ps.dev.p, ps.pin.p, words * 4, hipMemcpyHostToDevice, st));
+	// (the slot is busy from here on, whatever happens to the launches behind the copy: ADVICE r2)
+	HIPCHK (hipEventRecord (ps.done, st));
+	ps.pending = true;
 	e->plan_cur = slot;
 	e->tile_start = ps.dev.p; e->seg_tile = ps.dev.p + ts.size (); e->frag_tile = ps.dev.p + ts.size () + sg.size ();
 	e->tail_seg = e->frag_tile + ft.size ();
@@ -810,7 +813,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 			    : e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
 			                     : mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st);
 		}
-		if (lrc) return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ());
+		if (lrc) { e->plan.valid = false; return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ()); }
 		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 		mtr_gate_args ga;
@@ -820,7 +823,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ga.tail_tile = ebu ? pl.tail_tile : 0;
 		ga.fragm = (float) e->fragm; ga.integr = e->integr ? 1 : 0;
 		ga.max_scratch = e->gate_max.p;
-		if (mtr_launch_gate (ga, st)) return fail (MTR_ERR_HIP, "k_gate launch");
+		if (mtr_launch_gate (ga, st)) { e->plan.valid = false; return fail (MTR_ERR_HIP, "k_gate launch"); }
 		{
 			PlanSlot& ps = e->plan_slot[e->plan_cur];                 // k_gate is the plan's last reader
 			HIPCHK (hipEventRecord (ps.done, st));
@@ -1007,13 +1010,17 @@ int mtr_engine_results (mtr_engine* e, uint32_t first, uint32_t count, mtr_strea
 	if (rc) return rc;
 	if (!out) return fail (MTR_ERR_ARG, "null output");
 	if (count == 0) return MTR_OK;
-	std::vector<mtr_stream_state> h (count);
+	// (the one-stream snapshot path — an LV2 run () — touches no heap: the state came back with the block's own wait)
+	std::vector<mtr_stream_state> hv;
+	const mtr_stream_state* h = nullptr;
 	if (e->snap_valid && e->cfg.n_streams == 1) {
-		h[0] = e->pin_state.p[0];                                     // came back with the block's own wait
+		h = e->pin_state.p;
 	} else {
 		rc = mtr_engine_sync (e);
 		if (rc) return rc;
-		HIPCHK (hipMemcpy (h.data (), e->state.p + first, count * sizeof (mtr_stream_state), hipMemcpyDeviceToHost));
+		hv.resize (count);
+		HIPCHK (hipMemcpy (hv.data (), e->state.p + first, count * sizeof (mtr_stream_state), hipMemcpyDeviceToHost));
+		h = hv.data ();
 	}
 	for (uint32_t i = 0; i < count; ++i) {
 		const mtr_stream_state& s = h[i];
@@ -1068,15 +1075,17 @@ int mtr_engine_spectrum (mtr_engine* e, uint32_t first, uint32_t count, float* v
 	if (!(e->cfg.meters & MTR_METER_SPECTR30)) return fail (MTR_ERR_ARG, "no SPECTR30 in this engine");
 	if (count == 0) return MTR_OK;
 	const size_t n = (size_t) count * MTR_NBANDS;
-	std::vector<float> v (n), m (n);
+	std::vector<float> hv;
+	const float* v = nullptr; const float* m = nullptr;
 	if (e->snap_valid && e->cfg.n_streams == 1) {
-		memcpy (v.data (), e->pin_bank.p, n * 4);                     // came back with the block's own wait
-		memcpy (m.data (), e->pin_bank.p + MTR_NBANDS, n * 4);
+		v = e->pin_bank.p; m = e->pin_bank.p + MTR_NBANDS;            // came back with the block's own wait: no heap, no copy
 	} else {
 		rc = mtr_engine_sync (e);
 		if (rc) return rc;
-		HIPCHK (hipMemcpy (v.data (), e->bank_val.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
-		HIPCHK (hipMemcpy (m.data (), e->bank_max.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
+		hv.resize (2 * n);
+		HIPCHK (hipMemcpy (hv.data (), e->bank_val.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
+		HIPCHK (hipMemcpy (hv.data () + n, e->bank_max.p + (size_t) first * MTR_NBANDS, n * 4, hipMemcpyDeviceToHost));
+		v = hv.data (); m = hv.data () + n;
 	}
 	for (size_t i = 0; i < n; ++i) {
 		// spectrumlv2.c:240-247.  The stored val carries the +1e-20f of :237; above the -100 dB floor
