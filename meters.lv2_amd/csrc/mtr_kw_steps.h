@@ -5,17 +5,20 @@
 
 #include "mtr_wave.h"
 
-#define KW_STEP(p, y)                                   \
-	{                                                   \
-		v2f t_ = (p) + 1e-15f;                          \
-		t_ = t_ - b2 * z2;                              \
-		const v2f x_ = t_ - b1 * z1;                    \
-		v2f u_ = a1 * z1;                               \
-		u_ = u_ + a2 * z2;                              \
-		u_ = u_ - c4 * z4;                              \
-		u_ = u_ - c3 * z3;                              \
-		y = a0 * x_ + u_;                               \
-		z2 = z1; z1 = x_; z4 += z3; z3 += y;            \
+// (explicit fused multiply-adds, in kw_pair's association: the tail step of k_kw and the pairs round the same way whatever
+// -ffp-contract says — ADVICE r2)
+#define KW_STEP(p, y)                                                   \
+	{                                                                   \
+		v2f t_ = (p) + 1e-15f;                                          \
+		v2f u_ = (v2f) (a1) * z1;                                       \
+		t_ = __builtin_elementwise_fma (-(v2f) (b2), z2, t_);                   \
+		u_ = __builtin_elementwise_fma ((v2f) (a2), z2, u_);                    \
+		const v2f x_ = __builtin_elementwise_fma (-(v2f) (b1), z1, t_);         \
+		u_ = __builtin_elementwise_fma (-(v2f) (c4), z4, u_);                   \
+		const v2f z4n_ = z4 + z3;                                       \
+		u_ = __builtin_elementwise_fma (-(v2f) (c3), z3, u_);                   \
+		y = __builtin_elementwise_fma ((v2f) (a0), x_, u_);                     \
+		z2 = z1; z1 = x_; z4 = z4n_; z3 += y;                           \
 	}
 
 // Two K-weighting steps (frames n, n + 1 of every lane's run) as one hand-scheduled block.  What hipcc makes of the
@@ -31,7 +34,9 @@ __device__ __forceinline__ void kw_pair (v2f x0, v2f x1, v2f& zA, v2f& zB, v2f& 
                                          v2f b1, v2f b2, v2f c3, v2f c4, v2f eps, uint64_t upto, uint64_t before, int rl)
 {
 	v2f t, u, y, t2, u2;
+	uint64_t ex;                                   // the caller's lane mask: restored on the way out, whatever it was
 	asm volatile (
+		"s_mov_b64 %[ex], exec\n\t"
 		"s_cmp_gt_i32 %[rl], %[n0]\n\t"
 		"s_cselect_b64 exec, %[upto], %[before]\n\t"
 		"v_pk_add_f32 %[t], %[x0], %[eps]\n\t"
@@ -60,11 +65,11 @@ __device__ __forceinline__ void kw_pair (v2f x0, v2f x1, v2f& zA, v2f& zB, v2f& 
 		"s_nop 0\n\t"
 		"v_pk_add_f32 %[z3], %[z3], %[y]\n\t"
 		"v_pk_fma_f32 %[sj], %[y], %[y], %[sj]\n\t"
-		"s_mov_b64 exec, -1"
+		"s_mov_b64 exec, %[ex]"
 		: [zA] "+v"(zA), [zB] "+v"(zB), [z3] "+v"(z3), [z4] "+v"(z4), [sj] "+v"(sj),
-		  [t] "=&v"(t), [u] "=&v"(u), [y] "=&v"(y), [t2] "=&v"(t2), [u2] "=&v"(u2)
+		  [t] "=&v"(t), [u] "=&v"(u), [y] "=&v"(y), [t2] "=&v"(t2), [u2] "=&v"(u2), [ex] "=&s"(ex)
 		: [x0] "v"(x0), [x1] "v"(x1), [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [b1] "v"(b1), [b2] "v"(b2), [c3] "v"(c3), [c4] "v"(c4),
 		  [eps] "v"(eps), [upto] "s"(upto), [before] "s"(before), [rl] "s"(rl), [n0] "n"(N), [n1] "n"(N + 1)
-		: "scc");
+		: "scc");      // (exec is saved and restored inside the block: unchanged as far as the compiler can see)
 }
 
