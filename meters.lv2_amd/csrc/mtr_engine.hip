@@ -607,7 +607,8 @@ struct SegPlan {
 // aligned streams, and it must be a BATCH: the kernel's unit of parallelism is a lane, so it needs ~64 x the units of
 // k_kwtp16 to fill the chip.  The number of segments per stream is the one that minimises the modelled time — rounds of
 // resident waves x steps per wave, a warm-up step (K-filter only) at 0.3 of a full one — and the call takes this path
-// when that beats the model of k_kwtp16 (1.85 x the work per frame, measured: profiles/r03*, always a full machine).
+// when that beats the model of k_kwtp16 (1.2 x the time per frame when both fill the machine, measured: 11.7 vs 9.75 ms,
+// profiles/r03*; k_kwtp16's waves are a stream-tile each, so it fills the machine with any batch).
 static SegPlan seg_plan (const mtr_engine* e, const float* d_audio, uint64_t N, uint64_t stride)
 {
 	SegPlan sp;
@@ -632,7 +633,7 @@ static SegPlan seg_plan (const mtr_engine* e, const float* d_audio, uint64_t N, 
 		const double t = (double) rounds * ((double) n_main * spt + (g > 1 ? 0.3 * warm_steps : 0.0));
 		if (!bg || t < best) { best = t; bg = g; }
 	}
-	const double t6 = 1.85 * (double) S * (double) tiles * spt / (64.0 * e->seg_slots);
+	const double t6 = 1.2 * (double) S * (double) tiles * spt / (64.0 * e->seg_slots);
 	if (!e->cfg.tune_segments && best > t6) return sp;
 	sp.use = true;
 	sp.tiles = (uint32_t) tiles; sp.n_segs = (uint32_t) bg;
