@@ -68,11 +68,15 @@ static_assert (IN_STRIDE % 2 == 1 && OV_STRIDE % 2 == 1 && 48 % F == 0, "odd lan
 
 __device__ __forceinline__ v2f vabs (v2f v) { return v2f{fabsf (v.x), fabsf (v.y)}; }
 
-// `if (v > z) z += w * (v - z)` (truepeakdsp.cc:63-64): adding w * max (v - z, 0) is the same map
-__device__ __forceinline__ v2f attack (v2f z, v2f v, float w)
+// `if (v > z) z += w * (v - z)` (truepeakdsp.cc:63-64) is z <- max (z, (1 - w) z + w v): for v <= z the second argument is
+// <= z, for v > z it is the reference's update.  One fused multiply-add and a maximum ON the chain (the w v products do not
+// depend on the state and are formed off it) instead of subtract -> maximum -> multiply-add: the serial chain of a frame
+// is 9 dependent operations instead of 13.  (A rounding change of one ulp per step in a contraction: held to the same
+// 2e-6 as before, tests/test_gpu_parity.py::test_truepeak_ballistics_*.)
+__device__ __forceinline__ v2f attack (v2f z, v2f wv, float c)
 {
-	const v2f d = v - z;
-	return z + w * v2f{fmaxf (d.x, 0.f), fmaxf (d.y, 0.f)};
+	const v2f t = __builtin_elementwise_fma (v2f{c, c}, z, wv);
+	return v2f{fmaxf (z.x, t.x), fmaxf (z.y, t.y)};
 }
 
 // R outputs of the three non-trivial polyphase branches in the mirror-symmetric form of k_fused2
@@ -247,6 +251,21 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		z1 = v2f{z1.x > 20 ? 20 : (z1.x < 0 ? 0 : z1.x), z1.y > 20 ? 20 : (z1.y < 0 ? 0 : z1.y)};   // truepeakdsp.cc:54-55
 		z2 = v2f{z2.x > 20 ? 20 : (z2.x < 0 ? 0 : z2.x), z2.y > 20 ? 20 : (z2.y < 0 ? 0 : z2.y)};
 	}
+	// 32 streams per workgroup: the recurrence wave gives every (stream, CHANNEL) a lane of its own — lane l = stream l & 31,
+	// channel l >> 5 — instead of idling half its lanes with both channels packed in a v2f: there is no packed f32 maximum,
+	// so the packed form pays two v_max per attack; the scalar form is one v_fma + one v_max.  The serial chain is what
+	// bounds this kernel (every stream needs its frames' instructions one after the other): 20 scalar instructions per
+	// frame instead of 37 mixed ones.
+	const int rch = lane >> 5;
+	const uint32_t sl2 = s0 + (uint32_t) (lane & 31);
+	const bool owner2 = NS == 32 && sl2 < a.n_streams && (C == 2 || rch == 0);
+	mtr_stream_state* const st2 = a.state + (sl2 < a.n_streams ? sl2 : 0);
+	float y1 = 0.f, y2 = 0.f, ym = 0.f;
+	if (NS == 32 && !fir && owner2) {
+		y1 = st2->tpb_z1[rch]; y2 = st2->tpb_z2[rch];
+		y1 = y1 > 20 ? 20 : (y1 < 0 ? 0 : y1);
+		y2 = y2 > 20 ? 20 : (y2 < 0 ? 0 : y2);
+	}
 
 	if (fir) {
 		// prologue: the 48 frames before the call (47 of history, frame -48 is never multiplied by a non-zero
@@ -275,6 +294,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 #ifdef MTR_TPB_PROF
 	unsigned long long pr[4] = { 0, 0, 0, 0 };
 #endif
+	const float c1 = 1.0f - a.w1, c2 = 1.0f - a.w2;
 	int rd = 2, wr = 1;
 	for (int64_t t = 0; t <= n_chunks; ++t) {
 		PROF_NOW (c0_);
@@ -312,6 +332,30 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 			if (more) put (t + 1, wr, nxt);
 			PROF_NOW (c2_);
 			PROF_ADD (1, c2_ - c1_);
+		} else if (t > 0 && NS == 32) {
+			const int64_t c0 = (t - 1) * F;
+			const int nf = (int) min ((int64_t) F, (int64_t) a.n_frames - c0);
+			const float* const ov = reinterpret_cast<const float*> (ov_buf + ((t - 1) & 1) * NS * OV_STRIDE + (lane & 31) * OV_STRIDE) + rch;
+			float v[4] = { ov[0], ov[2], ov[4], ov[6] };
+#pragma unroll
+			for (int f = 0; f < F; ++f) {
+				float nv[4];
+				if (f + 1 < F) { nv[0] = ov[8 * f + 8]; nv[1] = ov[8 * f + 10]; nv[2] = ov[8 * f + 12]; nv[3] = ov[8 * f + 14]; }
+				if (f < nf) {                                            // wave-uniform: only the call's last chunk is short
+					float p1[4], p2[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) { p1[q] = a.w1 * v[q]; p2[q] = a.w2 * v[q]; }
+					y1 *= a.w3;
+					y2 *= a.w3;
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						y1 = fmaxf (y1, __builtin_fmaf (c1, y1, p1[q]));
+						y2 = fmaxf (y2, __builtin_fmaf (c2, y2, p2[q]));
+					}
+					ym = fmaxf (ym, y1 + y2);
+				}
+				if (f + 1 < F) { v[0] = nv[0]; v[1] = nv[1]; v[2] = nv[2]; v[3] = nv[3]; }
+			}
 		} else if (t > 0) {
 			const int64_t c0 = (t - 1) * F;
 			const int nf = (int) min ((int64_t) F, (int64_t) a.n_frames - c0);
@@ -323,12 +367,15 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 				v2f nv[4];
 				if (f + 1 < F) { nv[0] = ov[4 * f + 4]; nv[1] = ov[4 * f + 5]; nv[2] = ov[4 * f + 6]; nv[3] = ov[4 * f + 7]; }
 				if (f < nf) {                                            // wave-uniform: only the call's last chunk is short
+					v2f wv1[4], wv2[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) { wv1[q] = a.w1 * v[q]; wv2[q] = a.w2 * v[q]; }
 					z1 *= a.w3;
 					z2 *= a.w3;
 #pragma unroll
 					for (int q = 0; q < 4; ++q) {
-						z1 = attack (z1, v[q], a.w1);
-						z2 = attack (z2, v[q], a.w2);
+						z1 = attack (z1, wv1[q], c1);
+						z2 = attack (z2, wv2[q], c2);
 						if (NS == 64) pkp = v2f{fmaxf (pkp.x, v[q].x), fmaxf (pkp.y, v[q].y)};
 					}
 					const v2f zz = z1 + z2;
@@ -361,7 +408,17 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		atomicMax (&pk_sh[2 * srow + 1], __float_as_uint (pkp.y));
 	}
 	__syncthreads ();
-	if (!fir && owner) {
+	if (NS == 32) {
+		if (!fir && owner2) {
+			st2->tpb_z1[rch] = y1 + 1e-20f;                               // truepeakdsp.cc:86-87
+			st2->tpb_z2[rch] = y2 + 1e-20f;
+			st2->tpb_m[rch] = ym * a.g;                                   // :89, then read (m, p)
+			st2->tpb_p[rch] = __uint_as_float (pk_sh[2 * (lane & 31) + rch]);
+		}
+		if (C == 1 && !fir && lane < 32 && sl2 < a.n_streams) {         // mono engines keep a zero right channel
+			st2->tpb_z1[1] = 1e-20f; st2->tpb_z2[1] = 1e-20f; st2->tpb_m[1] = 0.f; st2->tpb_p[1] = 0.f;
+		}
+	} else if (!fir && owner) {
 		const v2f p = v2f{__uint_as_float (pk_sh[2 * srow]), __uint_as_float (pk_sh[2 * srow + 1])};
 		st->tpb_z1[0] = z1.x + 1e-20f; st->tpb_z1[1] = z1.y + 1e-20f;     // truepeakdsp.cc:86-87
 		st->tpb_z2[0] = z2.x + 1e-20f; st->tpb_z2[1] = z2.y + 1e-20f;
