@@ -13,8 +13,8 @@
 // tile).  Here a lane owns a whole TIME SEGMENT of a stream (the 64 lanes of a wave = 64 (stream, segment) units) and
 // walks it 16 frames per step:
 //   * the K-filter is the plain recurrence, 11 packed instructions per frame, state in registers; a segment that does
-//     not start the call is warmed up over the 0.2 s in front of it (slowest pole 0.99502 per sample: 1e-21 — what
-//     k_kwtp16's own time segments do), segment 0 starts from the carried state;
+//     not start the call is warmed up over the 0.1 s in front of it (slowest pole 0.99502 per sample: 4e-11;
+//     k_kwtp16 warms its own time segments the same way), segment 0 starts from the carried state;
 //   * the 16 new frames of a lane are ONE column of the block-Toeplitz product: rows = the 16 outputs, window = the
 //     lane's last 64 samples, which sit in a four-slot ring in LDS (f16 hi / lo words, 128 bytes per column and
 //     array, 16-byte chunks XOR-swizzled by the column: conflict-free ds_read_b128 / ds_write_b128).  One step = 64 columns = 4 blocks x 2 channels x 18 MFMAs;
@@ -24,8 +24,9 @@
 //     or NaN sample poisons only the columns it reaches;
 //   * no tile phases: every step is the same code, and the products of step j - 1 run UNDER the scalar and packed work
 //     of step j in one instruction stream (one wave per SIMD, all the registers, 38 KB of LDS) — the MFMA shadows
-//     carry the split, the maxima and half of the recurrence (tools/coissue.hip: one packed or two scalar VALU
-//     instructions per 16x16x32 MFMA are free);
+//     carry the split, the maxima and a quarter of the recurrence (tools/issue_model.hip: two independent full-rate or
+//     one half-rate VALU instruction per 16x16x32 MFMA cost 2 cycles; a packed-f32 one waits for the matrix pipe), the
+//     rest of the recurrence is one packed block per step, software-pipelined over frames;
 //   * loads: lane l reads its own 128 bytes per step (8 x global_load_dwordx4, one cache line), three steps ahead.
 //
 // The launch covers whole 50 ms tiles [0, n_main tiles per lane) of a call that starts on a fragment boundary; what is
@@ -33,6 +34,8 @@
 // same stream order (mtr_engine.hip).  Σ y² per tile leaves through tile_power exactly as from k_kwtp16, so k_gate does
 // not know which kernel ran.
 #include <hip/hip_runtime.h>
+
+#include <utility>
 
 #include "mtr_internal.h"
 #include "mtr_mfma16_fir.h"
@@ -57,9 +60,6 @@ constexpr int ARRB  = 64 * COLB;             // one array: HL | HR | LL | LR
 constexpr int BLKB  = 16 * COLB;             // 16 columns = one MFMA block
 constexpr int XCHG  = 4 * ARRB;              // exchange area: float [2 ch][4 blocks][4 kg][16 c]
 constexpr int LDS_BYTES = XCHG + 2048;
-#ifndef MTR_SEG_VPM
-#define MTR_SEG_VPM 1               // VALU instructions scheduled behind every MFMA of a step (tools/coissue.hip: one packed or two scalar are free)
-#endif
 
 typedef unsigned char lds_u8;          // (generic pointers into the dynamic LDS block: the compiler infers the address space)
 
@@ -103,22 +103,55 @@ __device__ __forceinline__ void kstep (const KCoef& k, KState& s, v2f p)
 	s.z2 = s.z1; s.z1 = x;
 }
 
-// the same step as eleven separate operations, for the hand-placed schedule of the main loop
-struct KTmp { v2f t, u, x, y; };
-template <int N>
-__device__ __forceinline__ void kop (const KCoef& k, KState& s, KTmp& w, v2f p)
+// The recurrence of one step — 16 frames x 11 operations — as ONE sequence for the hand-placed schedule of the main loop,
+// software-pipelined over frames: the x-chain of frame n + 1 (operations 0..4: it only needs x (n), x (n - 1)) runs between the
+// y-chain of frame n (5..10), so that no operation reads the result of one of its two predecessors (a dependent packed
+// operation issues after 8 cycles, an independent one after 5: tools/issue_model.hip).  Same operations, same operands,
+// same association as kstep — only their order in the instruction stream differs.
+//     0: t = p + eps         1: u = a1 z1          2: t -= b2 z2        3: u += a2 z2       4: x = t - b1 z1
+//     5: u -= c4 z4          6: z4 += z3           7: u -= c3 z3        8: y = a0 x + u     9: z3 += y      10: sj += y y
+constexpr int KOPS = 11 * R;
+struct KSeq {
+	int frame[KOPS], op[KOPS];
+	constexpr KSeq () : frame{}, op{}
+	{
+		int n = 0;
+		for (int o = 0; o < 5; ++o) { frame[n] = 0; op[n] = o; ++n; }
+		constexpr int ord[11][2] = { {5, 0}, {0, 1}, {6, 0}, {7, 0}, {1, 1}, {2, 1}, {8, 0}, {3, 1}, {4, 1}, {9, 0}, {10, 0} };
+		for (int f = 0; f < R; ++f)
+			for (int i = 0; i < 11; ++i) {
+				if (ord[i][1] && f + 1 == R) continue;
+				frame[n] = f + ord[i][1]; op[n] = ord[i][0]; ++n;
+			}
+	}
+};
+constexpr KSeq kseq_tab{};
+struct KWork { v2f t[R], u[R], y[R], x[R + 2]; };         // x[f + 2] = x of frame f; x[0], x[1] = z2, z1 carried into the step
+template <int OP>
+__device__ __forceinline__ void kopx (const KCoef& k, KState& s, KWork& w, const v2f (&p)[R], int f)
 {
-	if constexpr (N == 0) w.t = p + k.eps;
-	else if constexpr (N == 1) w.u = k.a1 * s.z1;
-	else if constexpr (N == 2) w.t = fma2 (-k.b2, s.z2, w.t);
-	else if constexpr (N == 3) w.u = fma2 (k.a2, s.z2, w.u);
-	else if constexpr (N == 4) w.x = fma2 (-k.b1, s.z1, w.t);
-	else if constexpr (N == 5) w.u = fma2 (-k.c4, s.z4, w.u);
-	else if constexpr (N == 6) s.z4 = s.z4 + s.z3;
-	else if constexpr (N == 7) w.u = fma2 (-k.c3, s.z3, w.u);
-	else if constexpr (N == 8) w.y = fma2 (k.a0, w.x, w.u);
-	else if constexpr (N == 9) s.z3 = s.z3 + w.y;
-	else { s.sj = fma2 (w.y, w.y, s.sj); s.z2 = s.z1; s.z1 = w.x; }
+	if constexpr (OP == 0) w.t[f] = p[f] + k.eps;
+	else if constexpr (OP == 1) w.u[f] = k.a1 * w.x[f + 1];
+	else if constexpr (OP == 2) w.t[f] = fma2 (-k.b2, w.x[f], w.t[f]);
+	else if constexpr (OP == 3) w.u[f] = fma2 (k.a2, w.x[f], w.u[f]);
+	else if constexpr (OP == 4) w.x[f + 2] = fma2 (-k.b1, w.x[f + 1], w.t[f]);
+	else if constexpr (OP == 5) w.u[f] = fma2 (-k.c4, s.z4, w.u[f]);
+	else if constexpr (OP == 6) s.z4 = s.z4 + s.z3;
+	else if constexpr (OP == 7) w.u[f] = fma2 (-k.c3, s.z3, w.u[f]);
+	else if constexpr (OP == 8) w.y[f] = fma2 (k.a0, w.x[f + 2], w.u[f]);
+	else if constexpr (OP == 9) s.z3 = s.z3 + w.y[f];
+	else s.sj = fma2 (w.y[f], w.y[f], s.sj);
+}
+
+// The lo word of the f16 split (mtr_mfma16_fir.h: lo_pair) as two separate instructions, so that the two that share an MFMA's
+// shadow are independent (the halves of one word are not: v_fma_mixhi keeps the word's low half).
+__device__ __forceinline__ void lo_first (uint32_t& lw, uint32_t hw, float x0)
+{
+	asm ("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(hw), "v"(x0));
+}
+__device__ __forceinline__ void lo_second (uint32_t& lw, uint32_t hw, float x1)
+{
+	asm ("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "v"(x1));
 }
 
 template <bool EBU>
@@ -222,9 +255,10 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	Scale scl, scr;
 	v2f pk0 = v2f{0.f, 0.f};                                           // phase 0: max |x[n - 24]|, exact
 	v2f pkf = v2f{0.f, 0.f};                                           // interpolated peaks that have left the scaled domain
-	float pm[4][2];                                                   // running |max| of the accumulators, scaled, per block and channel
+	float pm[4][2][2];                                                // running |max| of the accumulators, scaled, per block and channel: two
+	                                                                  // independent chains each (two dependent v_max3 in one MFMA's shadow cost 3 cycles)
 #pragma unroll
-	for (int b = 0; b < 4; ++b) { pm[b][0] = 0.f; pm[b][1] = 0.f; }
+	for (int b = 0; b < 4; ++b) { pm[b][0][0] = 0.f; pm[b][0][1] = 0.f; pm[b][1][0] = 0.f; pm[b][1][1] = 0.f; }
 
 	auto split_store = [&] (const v2f (&x)[R], int slot) __attribute__ ((always_inline)) {
 		const v2f sc = v2f{scl.sc, scr.sc};
@@ -280,9 +314,9 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		float* const X = reinterpret_cast<float*> (smem_ + XCHG);
 #pragma unroll
 		for (int b = 0; b < 4; ++b) {
-			X[((0 * 4 + b) * 4 + kg) * 16 + cc] = pm[b][0];
-			X[((1 * 4 + b) * 4 + kg) * 16 + cc] = pm[b][1];
-			pm[b][0] = 0.f; pm[b][1] = 0.f;
+			X[((0 * 4 + b) * 4 + kg) * 16 + cc] = fmaxf (pm[b][0][0], pm[b][0][1]);
+			X[((1 * 4 + b) * 4 + kg) * 16 + cc] = fmaxf (pm[b][1][0], pm[b][1][1]);
+			pm[b][0][0] = 0.f; pm[b][0][1] = 0.f; pm[b][1][0] = 0.f; pm[b][1][1] = 0.f;
 		}
 		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_wave_barrier ();
@@ -346,10 +380,10 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	};
 	// |max| of the accumulators of (block, channel) bc into pm
 	auto fold = [&] (const m16::f4 (&y)[3], int bc) __attribute__ ((always_inline)) {
-		float m = pm[bc >> 1][bc & 1];
+		float ma = pm[bc >> 1][bc & 1][0], mb = pm[bc >> 1][bc & 1][1];
 #pragma unroll
-		for (int p = 0; p < 3; ++p) { m = max3abs (m, y[p][0], y[p][1]); m = max3abs (m, y[p][2], y[p][3]); }
-		pm[bc >> 1][bc & 1] = m;
+		for (int p = 0; p < 3; ++p) { ma = max3abs (ma, y[p][0], y[p][1]); mb = max3abs (mb, y[p][2], y[p][3]); }
+		pm[bc >> 1][bc & 1][0] = ma; pm[bc >> 1][bc & 1][1] = mb;
 	};
 	// the products of the call's last step (nothing left to run under them); every chunk folds its predecessor's accumulators
 	auto products = [&]<int U> () __attribute__ ((always_inline)) {
@@ -411,19 +445,31 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		SPROF_NOW (c1_); SPROF_ADD (0, c1_ - c0_);
 
 		// Eight chunks, one per (block, channel) of the products of step j - 1.  THE SOURCE ORDER IS THE SCHEDULE (this TU
-		// is compiled without the machine schedulers, csrc/Makefile): behind every MFMA one packed or two scalar
-		// instructions of this step's own work, which is what issues for free in an MFMA's shadow (tools/coissue.hip):
-		//   MFMA 0-1: the scale of two frames    2: f16 hi pairs    3-4: lo pairs (v_fma_mix)    5: the next step's maxima
-		//   6-8: |max| of the previous chunk's accumulators    9-17: nine operations of the recurrence
-		// and behind the eighteenth the recurrence's other thirteen.
+		// is compiled without the machine schedulers, csrc/Makefile).  The issue model of one wave (tools/issue_model.hip,
+		// profiles/r03_issue_model.txt), in shader cycles per MFMA:
+		//     16x16x32 MFMA alone 17.2;  + 2 independent full-rate VALU (v_fma / v_mul / v_max3) 19.2;  + 3: 23.8;  + 2 DEPENDENT: 22.2
+		//     + 1 half-rate VALU (v_fma_mix, v_cvt_pk, 8 cycles alone) 18.5;  + 2 of them 26.5;  mixlo + mixhi of ONE word 31.3
+		//     + 1 v_pk_fma_f32: 34.3 (a packed-f32 instruction waits for the matrix pipe);  packed among themselves 5.1, 8.2 if
+		//     the next one reads the last one's result;  + 1 ds_read_b128: + 6
+		// So: behind every MFMA either two independent full-rate instructions (hipcc unpacks a packed one it finds there into its
+		// two halves) or ONE half-rate instruction, and everything that does not fit — most of the recurrence — in ONE packed
+		// block per step behind the last chunk (one wait for the matrix pipe per step instead of one per chunk):
+		//   MFMA 0-1: the scale of two frames    2-3: f16 hi words (v_cvt_pk)    4-7: lo words (v_fma_mix, one each)
+		//   8: the next step's maxima    9-11: |max| of the previous chunk's accumulators, two chains
+		//   12-17: six operations of the recurrence's sequence
 		const v2f sc2 = v2f{scl.sc, scr.sc};
 		uint32_t hl[R / 2], hr[R / 2], ll[R / 2], lr[R / 2];
 		float nl = 0.f, nr = 0.f;
 		const v2f (&xn)[R] = xq[(U + 1) & 3];
+		KWork kw;
+		kw.x[0] = ks.z2; kw.x[1] = ks.z1;
+		constexpr int KGAP = 6;                                     // operations of the recurrence behind the MFMAs of one chunk
+		auto kseq = [&]<int I> () __attribute__ ((always_inline)) {
+			if constexpr (EBU && I < KOPS) kopx<kseq_tab.op[I]> (kc, ks, kw, x, kseq_tab.frame[I]);
+		};
 		auto chunk = [&]<int BC> (m16::BFrag& Bc, m16::BFrag& Bn, m16::f4 (&yc)[3], m16::f4 (&yp)[3]) __attribute__ ((always_inline)) {
 			constexpr int PB = (BC + 7) & 7;
 			const v2f xa = x[2 * BC], xb = x[2 * BC + 1];
-			KTmp w;
 			if (PROD && BC < 7) fetch.template operator()<U> (Bn, BC + 1);
 #ifdef MTR_SEG_DBG_NOPROD                                        /* (elimination runs: no products) */
 #define MTR_M(I)
@@ -432,44 +478,38 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 #endif
 			MTR_M (0);  const v2f um = xa * sc2;
 			MTR_M (1);  const v2f vm = xb * sc2;
-			MTR_M (2);  hl[BC] = m16::hi_pair (um.x, vm.x); hr[BC] = m16::hi_pair (um.y, vm.y);
-			MTR_M (3);  ll[BC] = m16::lo_pair (hl[BC], um.x, vm.x);
-			MTR_M (4);  lr[BC] = m16::lo_pair (hr[BC], um.y, vm.y);
-			MTR_M (5);  nl = max3abs (nl, xn[2 * BC].x, xn[2 * BC + 1].x); nr = max3abs (nr, xn[2 * BC].y, xn[2 * BC + 1].y);
-			float m = pm[PB >> 1][PB & 1];
-			MTR_M (6);  if (PROD) { m = max3abs (m, yp[0][0], yp[0][1]); m = max3abs (m, yp[0][2], yp[0][3]); }
-			MTR_M (7);  if (PROD) { m = max3abs (m, yp[1][0], yp[1][1]); m = max3abs (m, yp[1][2], yp[1][3]); }
-			MTR_M (8);  if (PROD) { m = max3abs (m, yp[2][0], yp[2][1]); m = max3abs (m, yp[2][2], yp[2][3]); }
-			if (PROD) asm volatile ("" : "+v"(m));        // consumed here: the maxima must not sink behind the accumulators' next writers
-			pm[PB >> 1][PB & 1] = m;
+			MTR_M (2);  hl[BC] = m16::hi_pair (um.x, vm.x);
+			MTR_M (3);  hr[BC] = m16::hi_pair (um.y, vm.y);
+			MTR_M (4);  lo_first (ll[BC], hl[BC], um.x);
+			MTR_M (5);  lo_first (lr[BC], hr[BC], um.y);
+			MTR_M (6);  lo_second (ll[BC], hl[BC], vm.x);
+			MTR_M (7);  lo_second (lr[BC], hr[BC], vm.y);
+			MTR_M (8);  nl = max3abs (nl, xn[2 * BC].x, xn[2 * BC + 1].x); nr = max3abs (nr, xn[2 * BC].y, xn[2 * BC + 1].y);
+			float ma = pm[PB >> 1][PB & 1][0], mb = pm[PB >> 1][PB & 1][1];
+			MTR_M (9);  if (PROD) { ma = max3abs (ma, yp[0][0], yp[0][1]); mb = max3abs (mb, yp[0][2], yp[0][3]); }
+			MTR_M (10); if (PROD) { ma = max3abs (ma, yp[1][0], yp[1][1]); mb = max3abs (mb, yp[1][2], yp[1][3]); }
+			MTR_M (11); if (PROD) { ma = max3abs (ma, yp[2][0], yp[2][1]); mb = max3abs (mb, yp[2][2], yp[2][3]); }
+			if (PROD) asm volatile ("" : "+v"(ma), "+v"(mb));   // consumed here: the maxima must not sink behind the accumulators' next writers
+			pm[PB >> 1][PB & 1][0] = ma; pm[PB >> 1][PB & 1][1] = mb;
 			// The ring stores of this step ride in the last two chunks — behind the last operand fetch that still reads the
 			// slot they overwrite (chunk 6 fetches chunk 7's) — and the next step's first operands are fetched behind them:
 			// neither the stores' VGPR transfer nor the fetch's latency is left for the step's head and tail.
 #define MTR_ST(ARR, W_) \
 			if constexpr (BC == 6) *reinterpret_cast<uint4*> (smem + WS[U] + (ARR) * ARRB) = uint4{W_[0], W_[1], W_[2], W_[3]}; \
 			if constexpr (BC == 7) *reinterpret_cast<uint4*> (smem + (WS[U] ^ 16) + (ARR) * ARRB) = uint4{W_[4], W_[5], W_[6], W_[7]}
-			MTR_M (9);  if (EBU) kop<0> (kc, ks, w, xa);
-			MTR_M (10); if (EBU) kop<1> (kc, ks, w, xa);
+			MTR_M (12); kseq.template operator()<KGAP * BC + 0> ();
 			MTR_ST (0, hl);
-			MTR_M (11); if (EBU) kop<2> (kc, ks, w, xa);
-			MTR_M (12); if (EBU) kop<3> (kc, ks, w, xa);
+			MTR_M (13); kseq.template operator()<KGAP * BC + 1> ();
 			MTR_ST (1, hr);
-			MTR_M (13); if (EBU) kop<4> (kc, ks, w, xa);
-			MTR_M (14); if (EBU) kop<5> (kc, ks, w, xa);
+			MTR_M (14); kseq.template operator()<KGAP * BC + 2> ();
 			MTR_ST (2, ll);
-			MTR_M (15); if (EBU) kop<6> (kc, ks, w, xa);
-			MTR_M (16); if (EBU) kop<7> (kc, ks, w, xa);
+			MTR_M (15); kseq.template operator()<KGAP * BC + 3> ();
 			MTR_ST (3, lr);
+			MTR_M (16); kseq.template operator()<KGAP * BC + 4> ();
 			if constexpr (BC == 7) fetch.template operator()<(U + 1) & 3> (Bn, 0);      // (Bn of the last chunk = B0 of the next step)
-			MTR_M (17); if (EBU) kop<8> (kc, ks, w, xa);
+			MTR_M (17); kseq.template operator()<KGAP * BC + 5> ();
 #undef MTR_ST
 #undef MTR_M
-			if (EBU) {
-				kop<9> (kc, ks, w, xa); kop<10> (kc, ks, w, xa);
-				kop<0> (kc, ks, w, xb); kop<1> (kc, ks, w, xb); kop<2> (kc, ks, w, xb); kop<3> (kc, ks, w, xb);
-				kop<4> (kc, ks, w, xb); kop<5> (kc, ks, w, xb); kop<6> (kc, ks, w, xb); kop<7> (kc, ks, w, xb);
-				kop<8> (kc, ks, w, xb); kop<9> (kc, ks, w, xb); kop<10> (kc, ks, w, xb);
-			}
 		};
 		chunk.template operator()<0> (B0, B1, y0, y1);
 		SPROF_NOW (c2_); SPROF_ADD (1, c2_ - c1_);
@@ -480,6 +520,13 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		SPROF_NOW (c3_); SPROF_ADD (2, c3_ - c2_);
 		chunk.template operator()<7> (B1, B0, y1, y0);
 		SPROF_NOW (c4_); SPROF_ADD (3, c4_ - c3_);
+		// the rest of the recurrence's sequence: one packed block
+		if (EBU) {
+			[&]<int... Is> (std::integer_sequence<int, Is...>) __attribute__ ((always_inline)) {
+				(kseq.template operator()<8 * KGAP + Is> (), ...);
+			} (std::make_integer_sequence<int, KOPS - 8 * KGAP>{});
+			ks.z2 = kw.x[R]; ks.z1 = kw.x[R + 1];
+		}
 		asm volatile ("" : "+v"(nl), "+v"(nr));
 		ml = nl; mr = nr;
 		++j;
