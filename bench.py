@@ -304,20 +304,26 @@ def main():
                 seg = layout == 7 and eng.seg_stats()[0] > 0
                 # What binds: issue cycles of the SIMDs under the socket's power cap, not HBM.  Per 16 frames of 64 lanes (one step
                 # of a k_seg wave, 1024 stereo frames) the matrix pipe is busy 144 MFMAs x 16 cycles = 2304 cycles (three f16
-                # partial products for f32 grade); two scalar VALU instructions issue for free in an MFMA's shadow (tools/coissue.hip),
-                # the step's other ~210 scalar-equivalents of VALU work (K-weighting recurrence: 11 packed f32 per frame) do not:
-                # ~2.2 cycles each.  profiles/r03_kseg_step_cycles.txt has the measured step (4.3 k cycles) and the clock the power
-                # cap allows under this kernel (1.63 GHz of 2.4: profiles/r03_kseg_clock.txt) — both are properties of the committed
-                # profile, not of this run; this run contributes kernel_ms.
+                # partial products for f32 grade).  The issue model of one wave (tools/issue_model.hip, profiles/r03_issue_model.txt):
+                # an MFMA with the two full-rate (or one half-rate) VALU instructions that ride behind it issues every 19.2 cycles,
+                # the K-weighting recurrence that does not fit there (128 of its 176 packed instructions per step) runs as one
+                # packed block at 5.1 cycles per instruction + one 17-cycle wait for the matrix pipe, an LDS instruction costs 6.
+                # profiles/r03_kseg_step_cycles.txt has the measured step (4.03 k cycles; 3.11 k without the recurrence) and
+                # profiles/r03_kseg_clock.txt the clock the power cap allows under this kernel (1.56 - 1.60 GHz of 2.4) — both are
+                # properties of the committed profile, not of this run; this run contributes kernel_ms.
                 steps = S * T / 1024.0
                 n_simd = 1024.0
+                ebu_on = bool(meters & M.METER_EBU)
                 mfma_cycles = steps * 144 * 16 / n_simd
-                floor_cycles = steps * (144 * 16 + (210 * 2.2 if meters & M.METER_EBU else 0)) / n_simd
+                model_step = 144 * 19.2 + 40 * 6.0 + ((128 * 5.1 + 17) if ebu_on else 0)
+                floor_cycles = steps * model_step / n_simd
                 out["roofline"]["binding_roofline"] = {
-                    "bound": "SIMD issue cycles under the power cap: f16 MFMA (3 partial products) + the VALU work that does not fit the MFMA shadows",
+                    "bound": "SIMD issue cycles under the power cap: f16 MFMA (3 partial products) with two VALU riders each + the packed recurrence block + LDS",
+                    "mfma_pipe_cycles_per_step": 144 * 16, "issue_model_cycles_per_step": model_step,
+                    "profiled_cycles_per_step": (4028.5 if ebu_on else 3112.1) if seg else None,
                     "mfma_pipe_cycles_per_simd": mfma_cycles, "issue_floor_cycles_per_simd": floor_cycles,
-                    "kernel_ms_at_floor_and_2p4_ghz": floor_cycles / 2.4e6, "kernel_ms_at_floor_and_profiled_clock_1p63_ghz": floor_cycles / 1.63e6,
-                    "frac_of_floor_at_profiled_clock": (floor_cycles / 1.63e6) / k_ms,
+                    "kernel_ms_at_floor_and_2p4_ghz": floor_cycles / 2.4e6, "kernel_ms_at_floor_and_profiled_clock_1p58_ghz": floor_cycles / 1.58e6,
+                    "frac_of_floor_at_profiled_clock": (floor_cycles / 1.58e6) / k_ms,
                     "mfma_achieved_tflops": 2.0 * 16 * 16 * 32 * 144 * steps / (k_ms * 1e-3) / 1e12, "mfma_peak_tflops": 2500.0}
                 out["roofline"]["note"] = (("lane = time segment (k_seg): " if seg else "wave per (stream, segment) (k_kwtp16): ") +
                                            "K-weighting = the reference's recurrence in packed f32; interpolator on the matrix pipe at f32 grade "

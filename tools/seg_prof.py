@@ -22,7 +22,7 @@ with M.Engine(S, 48000.0, meters, tune_layout=7) as e:
     E.lib.mtr_debug_seg_prof(out)
     n = max(out[6], 1)
     names = ["step head: phase 0, scale check, operand fetch 0, 8 loads issued", "chunk 0 (waits for the stream)", "chunks 1-6",
-             "chunk 7", "ring stores, tile bookkeeping", "whole step"]
+             "chunk 7 (+ ring stores, next operand fetch)", "the recurrence's packed block (EBU), tile bookkeeping", "whole step"]
     print(what, "steps", n, "seg_stats", e.seg_stats())
     for i, nm in enumerate(names):
         print("  %-70s %9.1f cycles / step" % (nm, out[i] / n))
