@@ -118,6 +118,27 @@ def self_launch(n):
     os.execv(sys.executable, cmd)
 
 
+_REAL_STDOUT = None
+
+
+def own_stdout():
+    """Stdout carries ONE JSON line: libraries that write to the C-level stdout (RCCL prints its version banner there when a
+    communicator is created) are sent to stderr from here on; `emit` writes the line to the stdout the process was started with."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def dry_run(args, rank, world):
     """MTR_BENCH_DRY_RUN=1: the launcher logic without a GPU (tests/test_bench_launch.py) — ranks rendezvous over gloo, shard
     the job's streams, agree on the shards and rank 0 prints them.  Never a measurement."""
@@ -136,8 +157,7 @@ def dry_run(args, rank, world):
     else:
         rows = [mine]
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "streams_per_gpu": args.streams,
-                          "ranks": [[int(v) for v in r] for r in rows]}), flush=True)
+        emit({"dry_run": True, "n_gpus": world, "streams_per_gpu": args.streams, "ranks": [[int(v) for v in r] for r in rows]})
     if world > 1:
         dist.destroy_process_group()
 
@@ -165,6 +185,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)                                 # does not return
 
+    own_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -343,7 +364,7 @@ def main():
                                           "tpb": "k_tpb", "dr14": "k_dr14_sums", "kmeter": "k_kmeter_pieces"}.get(args.meters, "k_bank"),
                                "kernel_ms": k_ms}
         if mono:
-            print(json.dumps(out), flush=True)
+            emit(out)
             eng.close()
             return
         res = eng.results(0, 1)[0]
@@ -494,7 +515,7 @@ def main():
             out["prune"] = {"tile_passes": c, "skipped": k, "skipped_frac": k / max(c, 1),
                             "note": "exact branch-and-bound on L1*max|x|: identical peaks, data-dependent speed; "
                                     "NOT the default and not the dense headline number"}
-        print(json.dumps(out), flush=True)
+        emit(out)
     eng.close()
     if comm is not None:
         comm.close()
