@@ -134,7 +134,6 @@ struct mtr_engine {
 	uint32_t                   km_fpp = 0;
 	float                      km_fall = 0.f;
 	DevBuf<float>    fir_g;         // [3][48] taps in device memory
-	DevBuf<float>    fir_pmq;       // [3][24] the same in mirror-symmetric form (ballistics kernel)
 	DevBuf<uint16_t> m16_a;         // layouts 6, 7: hi / lo A fragments of the f32-grade MFMA interpolator (mtr_mfma16_fir.h)
 	DevBuf<uint32_t> prune_cnt;     // [4] interpolator tile passes considered / skipped, channel-blocks screened / completed
 	uint64_t         prune_tot[4] = { 0, 0, 0, 0 };
@@ -211,17 +210,6 @@ static int upload_consts (mtr_engine* e)
 	if (e->fir_g.reserve (144) || e->prune_cnt.reserve (4)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_g");
 	HIPCHK (hipMemset (e->prune_cnt.p, 0, 16));
 	HIPCHK (hipMemcpy (e->fir_g.p, g, sizeof (g), hipMemcpyHostToDevice));
-	{
-		// the same taps in the mirror-symmetric form (P, M, Q of mtr_fused2.hip) for the ballistics kernel
-		float pmq[3][24];
-		for (int i = 0; i < 24; ++i) {
-			pmq[0][i] = (float) (((double) g[0][i] + (double) g[0][47 - i]) * 0.5);
-			pmq[1][i] = (float) (((double) g[0][i] - (double) g[0][47 - i]) * 0.5);
-			pmq[2][i] = g[1][i];
-		}
-		if (e->fir_pmq.reserve (72)) return fail (MTR_ERR_NOMEM, "hipMalloc fir_pmq");
-		HIPCHK (hipMemcpy (e->fir_pmq.p, pmq, sizeof (pmq), hipMemcpyHostToDevice));
-	}
 	{
 		// and as A fragments of the matrix-pipe interpolator
 		std::vector<uint16_t> a16 (MTR_M16_A_HALVES);
@@ -889,7 +877,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (tpb) {
 		mtr_tpb_args ta;
 		ta.audio = d_audio; ta.stride = stride; ta.n_frames = n_frames;
-		ta.hist = e->fir_hist[e->hist_cur].p; ta.fir_g = e->fir_g.p; ta.fir_pmq = e->fir_pmq.p; ta.state = e->state.p;
+		ta.hist = e->fir_hist[e->hist_cur].p; ta.mfma_a = e->m16_a.p; ta.state = e->state.p;
 		ta.n_streams = S; ta.n_channels = e->cfg.n_channels;
 		ta.w1 = e->tpb_w[0]; ta.w2 = e->tpb_w[1]; ta.w3 = e->tpb_w[2]; ta.g = e->tpb_w[3];
 		if (mtr_launch_tpb (ta, st)) return fail (MTR_ERR_HIP, "k_tpb launch");

@@ -159,8 +159,7 @@ struct mtr_tpb_args {
 	const float*    audio;        /* [S][stride][C] */
 	uint64_t        stride, n_frames;
 	const float*    hist;         /* [S][47][2] */
-	const float*    fir_g;        /* [3][48] */
-	const float*    fir_pmq;      /* [3][24] mirror-symmetric form: P, M, Q (mtr_fused2.hip) */
+	const uint16_t* mfma_a;       /* A fragments of the matrix-pipe interpolator (mtr_mfma16_fir.h) */
 	mtr_stream_state* state;
 	uint32_t        n_streams, n_channels;
 	float           w1, w2, w3, g;   /* truepeakdsp.cc:154-157 */

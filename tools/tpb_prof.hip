@@ -1,5 +1,5 @@
 // tools/tpb_prof.hip — where does a chunk of k_tpb go?  Builds the kernel with cycle counters per wave
-// (fetch+interpolate / wait for rows + put / barrier wait / total) and prints them for workgroup 0.
+// (work / barrier wait / total) and prints them for workgroup 0.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imeters.lv2_amd/csrc tools/tpb_prof.hip -o tools/tpb_prof
 #define MTR_TPB_PROF 1
 #include "../meters.lv2_amd/csrc/mtr_tpb.hip"
@@ -12,10 +12,10 @@ int main (int argc, char** argv)
 {
 	const uint32_t S = argc > 1 ? atoi (argv[1]) : 8192;
 	const uint64_t T = argc > 2 ? atoll (argv[2]) : 48000;
-	float *audio, *hist, *pmq; mtr_stream_state* st;
+	float *audio, *hist; uint16_t* afr; mtr_stream_state* st;
 	hipMalloc (&audio, (size_t) S * T * 8);
 	hipMalloc (&hist, (size_t) S * MTR_FIR_HALO * 8);
-	hipMalloc (&pmq, 72 * 4);
+	hipMalloc (&afr, MTR_M16_A_HALVES * 2);
 	hipMalloc (&st, (size_t) S * sizeof (mtr_stream_state));
 	hipMemset (hist, 0, (size_t) S * MTR_FIR_HALO * 8);
 	hipMemset (st, 0, (size_t) S * sizeof (mtr_stream_state));
@@ -24,10 +24,12 @@ int main (int argc, char** argv)
 	for (auto& v : h) { r = r * 1664525u + 1013904223u; v = ((int) (r >> 8) - (1 << 23)) / 8388608.f; }
 	for (size_t o = 0; o < (size_t) S * T * 2; o += h.size ())
 		hipMemcpy (audio + o, h.data (), std::min (h.size (), (size_t) S * T * 2 - o) * 4, hipMemcpyHostToDevice);
-	std::vector<float> taps (72, 0.01f);
-	hipMemcpy (pmq, taps.data (), 72 * 4, hipMemcpyHostToDevice);
+	std::vector<float> taps (144, 0.01f);
+	std::vector<uint16_t> a16 (MTR_M16_A_HALVES);
+	mtr_m16_build_a (taps.data (), a16.data ());
+	hipMemcpy (afr, a16.data (), a16.size () * 2, hipMemcpyHostToDevice);
 	mtr_tpb_args a{};
-	a.audio = audio; a.stride = T; a.n_frames = T; a.hist = hist; a.fir_g = nullptr; a.fir_pmq = pmq; a.state = st;
+	a.audio = audio; a.stride = T; a.n_frames = T; a.hist = hist; a.mfma_a = afr; a.state = st;
 	a.n_streams = S; a.n_channels = 2; a.w1 = 0.0208f; a.w2 = 0.0896f; a.w3 = 0.99996f; a.g = 0.502f;
 	hipEvent_t e0, e1; hipEventCreate (&e0); hipEventCreate (&e1);
 	mtr_launch_tpb (a, nullptr);
@@ -37,13 +39,11 @@ int main (int argc, char** argv)
 	hipEventRecord (e1);
 	hipDeviceSynchronize ();
 	float ms; hipEventElapsedTime (&ms, e0, e1);
-	unsigned long long pr[16][4];
+	unsigned long long pr[8][4];
 	hipMemcpyFromSymbol (pr, HIP_SYMBOL (g_tpb_prof), sizeof pr);
-	const double nchunk = (double) ((T + F - 1) / F + 1);
+	const double nchunk = (double) ((T + F - 1) / F + 2);
 	printf ("S=%u T=%llu: %.3f ms, %.0f ns per chunk of %d frames\n", S, (unsigned long long) T, ms, ms * 1e6 / nchunk, F);
-	printf ("s_memtime ticks per chunk (100 MHz clock? compare the total with ns):\n wave  fetch+interp (rec: chain)  rows+put  fetch only (rec: barrier)  total\n");
-	for (int w = 0; w < NW; ++w)
-		printf ("  %2d  %7.1f  %7.1f  %7.1f  %7.1f   simd %llu item %lld of %llu\n", w, pr[w][0] / nchunk, pr[w][1] / nchunk, pr[w][2] / nchunk,
-		        pr[w][3] / nchunk, pr[8 + w][0], (long long) pr[8 + w][1], pr[8 + w][2]);
+	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (wave 0: the chains; 1, 2, 3, 7: one block of products each; 4, 5, 6: maps of 4, 6, 6 frames; 4 fetches)\n");
+	for (int w = 0; w < NW; ++w) printf ("  %2d  %7.1f  %7.1f  %7.1f\n", w, pr[w][0] / nchunk, pr[w][2] / nchunk, pr[w][3] / nchunk);
 	return 0;
 }
