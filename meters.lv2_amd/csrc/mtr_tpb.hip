@@ -127,7 +127,24 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		pdst[i] = row * RSTRIDE + pfr[i];                                // (stereo: the right channel's column is 32 further)
 	}
 	float4 pv[NP];
+	// prow[i] points at the piece's first frame of chunk 0; a chunk further is F frames further.  Whole chunks take the
+	// path without bounds arithmetic (a row of a stream past the batch re-reads stream s0 and is zeroed when it is stored).
+	const float* pcur[NP];
+#pragma unroll
+	for (int i = 0; i < NP; ++i) pcur[i] = prow[i] + (size_t) pfr[i] * C;
 	auto fetch = [&] (int64_t j) {
+		if ((j + 1) * F <= n_frames) {
+#pragma unroll
+			for (int i = 0; i < NP; ++i) {
+				const float* const q = pcur[i] + (size_t) j * (F * C);
+				if (C == 2) {
+					const v2f u = *reinterpret_cast<const v2f*> (q), v = *reinterpret_cast<const v2f*> (q + 2);
+					pv[i] = float4{u.x, u.y, v.x, v.y};
+				} else pv[i] = float4{q[0], q[1], q[2], q[3]};
+				if (!plive[i]) pv[i] = float4{0.f, 0.f, 0.f, 0.f};
+			}
+			return;
+		}
 #pragma unroll
 		for (int i = 0; i < NP; ++i) {
 			const int64_t f = j * F + pfr[i];
@@ -173,8 +190,14 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		float mx = 0.f;
 #pragma unroll
 		for (int q = 0; q < 4; ++q) mx = max3f (mx, max3f (fabsf (x[q].x), fabsf (x[q].y), fabsf (x[q].z)), fabsf (x[q].w));
-		mx = __builtin_fmaxf (mx, __shfl_xor (mx, 16));
-		mx = __builtin_fmaxf (mx, __shfl_xor (mx, 32));
+		// ... over the four lanes that hold the column's window (c, c + 16, c + 32, c + 48): two VALU lane swaps, not two trips through the LDS crossbar
+		{
+			typedef unsigned u2 __attribute__ ((ext_vector_type (2)));
+			const u2 r16 = __builtin_amdgcn_permlane16_swap (__float_as_uint (mx), __float_as_uint (mx), false, false);
+			mx = __builtin_fmaxf (__uint_as_float (r16.x), __uint_as_float (r16.y));
+			const u2 r32 = __builtin_amdgcn_permlane32_swap (__float_as_uint (mx), __float_as_uint (mx), false, false);
+			mx = __builtin_fmaxf (__uint_as_float (r32.x), __uint_as_float (r32.y));
+		}
 		const int e = (int) (__float_as_uint (mx) >> 23);
 		const int se = min (238, 257 - e);
 		const float sc = __uint_as_float ((uint32_t) se << 23), un = __uint_as_float ((uint32_t) (239 - se) << 23);
@@ -189,13 +212,15 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		B.l0 = uint4{lw[0], lw[1], lw[2], lw[3]}; B.l1 = uint4{lw[4], lw[5], lw[6], lw[7]};
 		m16::f4 y[3];
 		m16::block (A, B, y);
-		unsigned char* const dst = vbuf + par * VBUF_B + ((4 * kg) * 2 * NCOL + 16 * b + cc) * 16;
 		const float xr[4] = { x0.x, x0.y, x0.z, x0.w };
 		const float u1 = un * a.w1, u2 = un * a.w2;                          // (un is a power of two: exact)
 		float pm = 0.f, px = 0.f;
+		unsigned char* const dst = vbuf + par * VBUF_B + ((4 * kg) * 2 * NCOL + 16 * b + cc) * 16;
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
-			if (r < nfl) { px = __builtin_fmaxf (px, fabsf (xr[r])); pm = max3f (max3f (pm, fabsf (y[0][r]), fabsf (y[1][r])), fabsf (y[2][r]), pm); }   // truepeakdsp.cc:65
+			const float keep = r < nfl ? 1.f : 0.f;
+			px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
+			pm = __builtin_fmaxf (pm, max3f (fabsf (y[0][r]), fabsf (y[1][r]), fabsf (y[2][r])) * keep);      // truepeakdsp.cc:65
 			*reinterpret_cast<float4*> (dst + (r * 2 + 0) * NCOL * 16) = float4{fabsf (xr[r]) * a.w1, fabsf (xr[r]) * a.w2, fabsf (y[0][r]) * u1, fabsf (y[0][r]) * u2};
 			*reinterpret_cast<float4*> (dst + (r * 2 + 1) * NCOL * 16) = float4{fabsf (y[1][r]) * u1, fabsf (y[1][r]) * u2, fabsf (y[2][r]) * u1, fabsf (y[2][r]) * u2};
 		}
@@ -269,14 +294,15 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		}
 	};
 	int slot_w = 32, slot_p = F % RING;                                  // window start of chunk t; where chunk t + 1 goes
-	for (int64_t t = 0; t < n_chunks + 2; ++t) {
+	constexpr int LAG = 2;                                               // chunks between the products and the chains
+	for (int64_t t = 0; t < n_chunks + LAG; ++t) {
 		PROF_NOW (c0_);
 		const int par = (int) (t & 1);
 		if (wid == 0) {
-			if (t >= 2 && !MTR_TPB_DBG_NOCHAIN) {
-				const int64_t left = n_frames - (t - 2) * F;
-				if (left >= F) chain.template operator()<true> (par, F);
-				else chain.template operator()<false> (par, (int) left);
+			if (t >= LAG && !MTR_TPB_DBG_NOCHAIN) {
+				const int64_t left = n_frames - (t - LAG) * F;
+				if (left >= F) chain.template operator()<true> (par ^ (LAG & 1), F);
+				else chain.template operator()<false> (par ^ (LAG & 1), (int) left);
 			}
 		} else if (wid <= 3 || wid == 7) {
 			if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {

@@ -31,7 +31,7 @@ for p in ("pmc1","pmc2","pmc3","pmc4","pmc5","pmc6"):
             acc[k][0] += float(row.get("Counter_Value", 0)); acc[k][1] += 1
         print("==", p)
         for k, (v, n) in sorted(acc.items()):
-            if any(t in k[0] for t in ("k_seg", "k_kwtp", "k_kw", "k_gate", "k_bank", "k_fused")):
+            if any(t in k[0] for t in ("k_seg", "k_kwtp", "k_kw", "k_gate", "k_bank", "k_fused", "k_tpb")):
                 print(k, "avg/dispatch = %.5g" % (v / n), "n =", n)
 PY
 cat $out/summary.txt
