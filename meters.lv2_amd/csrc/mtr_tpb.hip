@@ -175,60 +175,76 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// ---- the products (waves 1, 2, 3, 7) and the per-frame maps (waves 4, 5, 6; lane = column) -----------------------------
 	const int cc = lane & 15, kg = lane >> 4;
 	m16::AFrag A;
-	if ((wid >= 1 && wid <= 3) || wid == 7) A.load (a.mfma_a, lane);
+	if ((wid >= 1 && wid <= 3) || wid == 7) A.load (a.mfma_a, lane);          // (whoever runs products)
 	// values of chunk j, block b (columns 16 b + cc; this lane: frames 4 kg .. + 3) -> vbuf
-	float pk = 0.f;                                                      // raw peak of the values this lane produced (column 16 b + cc)
-	auto products = [&] (int par, int w0, int b, int nfl) {              // w0 = ring slot of window position 0 = frame 16 j - 48; par = j & 1;
+	// NB blocks per call, stage by stage for all of them.  One block is a dependent sequence (ring read -> window maximum -> scale ->
+	// split -> 18 MFMAs -> un-scale -> store) that leaves most issue slots of its wave empty — but two blocks in one wave (NB = 2) cost
+	// more than two waves with one block each sharing a SIMD (40.3 vs 35.5 ms): NB = 1 is what runs.
+	float pk[2] = { 0.f, 0.f };                                          // raw peaks of the values this lane produced (column cc of its blocks)
+	auto products = [&]<int NB> (int par, int w0, int b0, int nfl) {     // w0 = ring slot of window position 0 = frame 16 j - 48; par = j & 1;
 	                                                                     // nfl = how many of this lane's four frames belong to the call
-		const float* const col = ring + (16 * b + cc) * RSTRIDE;
-		float4 x[4];                                                     // positions 32 st + 8 kg .. + 7, st = 0, 1
+		float4 x[NB][4], x0[NB];                                         // positions 32 st + 8 kg .. + 7, st = 0, 1; x[n - 24] of this lane's four frames
 #pragma unroll
-		for (int q = 0; q < 4; ++q) { int o = w0 + 32 * (q >> 1) + 8 * kg + 4 * (q & 1); o -= o >= RING ? RING : 0; x[q] = *reinterpret_cast<const float4*> (col + o); }
-		int o0 = w0 + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0;
-		const float4 x0 = *reinterpret_cast<const float4*> (col + o0);                              // x[n - 24] of this lane's four frames
+		for (int n = 0; n < NB; ++n) {
+			const float* const col = ring + (16 * (b0 + n) + cc) * RSTRIDE;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { int o = w0 + 32 * (q >> 1) + 8 * kg + 4 * (q & 1); o -= o >= RING ? RING : 0; x[n][q] = *reinterpret_cast<const float4*> (col + o); }
+			int o0 = w0 + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0;
+			x0[n] = *reinterpret_cast<const float4*> (col + o0);
+		}
 		// the column's scale: a power of two that puts the window's maximum into [2^3, 2^4) — 22 bits of every sample that matters
-		float mx = 0.f;
+		float sc[NB], un[NB];
 #pragma unroll
-		for (int q = 0; q < 4; ++q) mx = max3f (mx, max3f (fabsf (x[q].x), fabsf (x[q].y), fabsf (x[q].z)), fabsf (x[q].w));
-		// ... over the four lanes that hold the column's window (c, c + 16, c + 32, c + 48): two VALU lane swaps, not two trips through the LDS crossbar
-		{
+		for (int n = 0; n < NB; ++n) {
+			float mx = 0.f;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) mx = max3f (mx, max3f (fabsf (x[n][q].x), fabsf (x[n][q].y), fabsf (x[n][q].z)), fabsf (x[n][q].w));
+			// ... over the four lanes that hold the column's window (c, c + 16, c + 32, c + 48): two VALU lane swaps, not two trips through the LDS crossbar
 			typedef unsigned u2 __attribute__ ((ext_vector_type (2)));
 			const u2 r16 = __builtin_amdgcn_permlane16_swap (__float_as_uint (mx), __float_as_uint (mx), false, false);
 			mx = __builtin_fmaxf (__uint_as_float (r16.x), __uint_as_float (r16.y));
 			const u2 r32 = __builtin_amdgcn_permlane32_swap (__float_as_uint (mx), __float_as_uint (mx), false, false);
 			mx = __builtin_fmaxf (__uint_as_float (r32.x), __uint_as_float (r32.y));
+			const int e = (int) (__float_as_uint (mx) >> 23);
+			const int se = min (238, 257 - e);
+			sc[n] = __uint_as_float ((uint32_t) se << 23); un[n] = __uint_as_float ((uint32_t) (239 - se) << 23);
 		}
-		const int e = (int) (__float_as_uint (mx) >> 23);
-		const int se = min (238, 257 - e);
-		const float sc = __uint_as_float ((uint32_t) se << 23), un = __uint_as_float ((uint32_t) (239 - se) << 23);
-		m16::BFrag B;
-		uint32_t hw[8], lw[8];
+		m16::BFrag B[NB];
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			m16::split_pair (x[q].x * sc, x[q].y * sc, hw[2 * q], lw[2 * q]);
-			m16::split_pair (x[q].z * sc, x[q].w * sc, hw[2 * q + 1], lw[2 * q + 1]);
-		}
-		B.h0 = uint4{hw[0], hw[1], hw[2], hw[3]}; B.h1 = uint4{hw[4], hw[5], hw[6], hw[7]};
-		B.l0 = uint4{lw[0], lw[1], lw[2], lw[3]}; B.l1 = uint4{lw[4], lw[5], lw[6], lw[7]};
-		m16::f4 y[3];
-		m16::block (A, B, y);
-		const float xr[4] = { x0.x, x0.y, x0.z, x0.w };
-		const float u1 = un * a.w1, u2 = un * a.w2;                          // (un is a power of two: exact)
-		float pm = 0.f, px = 0.f;
-		unsigned char* const dst = vbuf + par * VBUF_B + ((4 * kg) * 2 * NCOL + 16 * b + cc) * 16;
+		for (int n = 0; n < NB; ++n) {
+			uint32_t hw[8], lw[8];
 #pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const float keep = r < nfl ? 1.f : 0.f;
-			px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
-			pm = __builtin_fmaxf (pm, max3f (fabsf (y[0][r]), fabsf (y[1][r]), fabsf (y[2][r])) * keep);      // truepeakdsp.cc:65
-			*reinterpret_cast<float4*> (dst + (r * 2 + 0) * NCOL * 16) = float4{fabsf (xr[r]) * a.w1, fabsf (xr[r]) * a.w2, fabsf (y[0][r]) * u1, fabsf (y[0][r]) * u2};
-			*reinterpret_cast<float4*> (dst + (r * 2 + 1) * NCOL * 16) = float4{fabsf (y[1][r]) * u1, fabsf (y[1][r]) * u2, fabsf (y[2][r]) * u1, fabsf (y[2][r]) * u2};
+			for (int q = 0; q < 4; ++q) {
+				m16::split_pair (x[n][q].x * sc[n], x[n][q].y * sc[n], hw[2 * q], lw[2 * q]);
+				m16::split_pair (x[n][q].z * sc[n], x[n][q].w * sc[n], hw[2 * q + 1], lw[2 * q + 1]);
+			}
+			B[n].h0 = uint4{hw[0], hw[1], hw[2], hw[3]}; B[n].h1 = uint4{hw[4], hw[5], hw[6], hw[7]};
+			B[n].l0 = uint4{lw[0], lw[1], lw[2], lw[3]}; B[n].l1 = uint4{lw[4], lw[5], lw[6], lw[7]};
 		}
-		pk = max3f (pk, px, pm * un);
+		m16::f4 y[NB][3];
+#pragma unroll
+		for (int n = 0; n < NB; ++n) m16::block (A, B[n], y[n]);
+#pragma unroll
+		for (int n = 0; n < NB; ++n) {
+			unsigned char* const dst = vbuf + par * VBUF_B + ((4 * kg) * 2 * NCOL + 16 * (b0 + n) + cc) * 16;
+			const float xr[4] = { x0[n].x, x0[n].y, x0[n].z, x0[n].w };
+			const float u1 = un[n] * a.w1, u2 = un[n] * a.w2;                // (un is a power of two: exact)
+			float pm = 0.f, px = 0.f;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const float keep = r < nfl ? 1.f : 0.f;
+				px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
+				pm = __builtin_fmaxf (pm, max3f (fabsf (y[n][0][r]), fabsf (y[n][1][r]), fabsf (y[n][2][r])) * keep);      // truepeakdsp.cc:65
+				*reinterpret_cast<float4*> (dst + (r * 2 + 0) * NCOL * 16) = float4{fabsf (xr[r]) * a.w1, fabsf (xr[r]) * a.w2, fabsf (y[n][0][r]) * u1, fabsf (y[n][0][r]) * u2};
+				*reinterpret_cast<float4*> (dst + (r * 2 + 1) * NCOL * 16) = float4{fabsf (y[n][1][r]) * u1, fabsf (y[n][1][r]) * u2, fabsf (y[n][2][r]) * u1, fabsf (y[n][2][r]) * u2};
+			}
+			pk[n] = max3f (pk[n], px, pm * un[n]);
+		}
 	};
 
 	const v2f AA = v2f{a1, a2};
 	auto maps = [&]<int F0, int F1> (int par) {
+		if constexpr (F1 > F0) {
 		const unsigned char* const src = vbuf + par * VBUF_B + lane * 16;
 		unsigned char* const dst = cbuf + par * CBUF_B + lane * 16;
 		float4 va[F1 - F0], vb[F1 - F0];                                 // every value first: the stores below would otherwise order the reads
@@ -249,6 +265,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		for (int f = F0; f < F1; ++f) {
 			*reinterpret_cast<float4*> (dst + (f * 2 + 0) * NCOL * 16) = float4{g1[f - F0].x, g1[f - F0].y, g2[f - F0].x, g2[f - F0].y};
 			*reinterpret_cast<float4*> (dst + (f * 2 + 1) * NCOL * 16) = float4{g3[f - F0].x, g3[f - F0].y, g4[f - F0].x, g4[f - F0].y};
+		}
 		}
 	};
 
@@ -307,7 +324,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		} else if (wid <= 3 || wid == 7) {
 			if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
 				const int64_t left = n_frames - t * F - 4 * kg;                 // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
-				products (par, slot_w, wid == 7 ? 3 : wid - 1, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
+				products.template operator()<1> (par, slot_w, wid == 7 ? 3 : wid - 1, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
 			}
 		} else {
 			const bool more = t + 1 < n_chunks;
@@ -335,8 +352,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	uint32_t* const pk_sh = reinterpret_cast<uint32_t*> (ring);          // the ring is spent
 	if (wid == 0) pk_sh[lane] = 0u;
 	__syncthreads ();
-	if (wid <= 3 && wid >= 1) atomicMax (&pk_sh[16 * (wid - 1) + cc], __float_as_uint (pk));
-	if (wid == 7) atomicMax (&pk_sh[48 + cc], __float_as_uint (pk));
+	if (wid <= 3 && wid >= 1) atomicMax (&pk_sh[16 * (wid - 1) + cc], __float_as_uint (pk[0]));
+	if (wid == 7) atomicMax (&pk_sh[48 + cc], __float_as_uint (pk[0]));
 	__syncthreads ();
 	if (wid == 0 && owner) {
 		st->tpb_z1[ch] = z1 + 1e-20f;                                    // truepeakdsp.cc:86-87
