@@ -630,6 +630,14 @@ static SegPlan seg_plan (const mtr_engine* e, const float* d_audio, uint64_t N, 
 	return sp;
 }
 
+// A launch behind build_plan's upload failed: the slot stays busy until the stream has passed this point, the plan is not reused.
+static void plan_abort (mtr_engine* e, hipStream_t st)
+{
+	PlanSlot& ps = e->plan_slot[e->plan_cur];
+	if (ps.done && hipEventRecord (ps.done, st) == hipSuccess) ps.pending = true;
+	e->plan.valid = false;
+}
+
 // Tiling plan for a call of n_frames starting with `frcnt` frames left in the open fragment.  body_tiles > 0: the call
 // starts on a fragment boundary and its first body_tiles tiles are whole fragments (k_seg's part), whatever their length.
 static int build_plan (mtr_engine* e, uint64_t N, uint32_t body_tiles, hipStream_t st)
@@ -695,9 +703,9 @@ static int build_plan (mtr_engine* e, uint64_t N, uint32_t body_tiles, hipStream
 	memcpy (ps.pin.p + ts.size () + sg.size (), ft.data (), ft.size () * 4);
 	memcpy (ps.pin.p + ts.size () + sg.size () + ft.size (), tseg, 8);
 	HIPCHK (hipMemcpyAsync (ps.dev.p, ps.pin.p, words * 4, hipMemcpyHostToDevice, st));
-	// (the slot is busy from here on, whatever happens to the launches behind the copy: ADVICE r2)
-	HIPCHK (hipEventRecord (ps.done, st));
-	ps.pending = true;
+	// (the slot is busy from here on: its `done` event is recorded behind the plan's last reader, k_gate — or by plan_abort ()
+	// if a launch behind this copy fails, so that the slot is never handed out again under a pending upload: ADVICE r2.
+	// One hipEventRecord per call, not two: it is 2-3 us of an LV2 run ().)
 	e->plan_cur = slot;
 	e->tile_start = ps.dev.p; e->seg_tile = ps.dev.p + ts.size (); e->frag_tile = ps.dev.p + ts.size () + sg.size ();
 	e->tail_seg = e->frag_tile + ft.size ();
@@ -802,7 +810,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 			    : e->layout == 4 ? mtr_launch_kw (e->run, fa, S * pl.n_segs, st)
 			                     : mtr_launch_fused2 (e->run, ebu, tp, fa, S * pl.n_segs, st);
 		}
-		if (lrc) { e->plan.valid = false; return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ()); }
+		if (lrc) { plan_abort (e, st); return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ()); }
 		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 		mtr_gate_args ga;
@@ -812,7 +820,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ga.tail_tile = ebu ? pl.tail_tile : 0;
 		ga.fragm = (float) e->fragm; ga.integr = e->integr ? 1 : 0;
 		ga.max_scratch = e->gate_max.p;
-		if (mtr_launch_gate (ga, st)) { e->plan.valid = false; return fail (MTR_ERR_HIP, "k_gate launch"); }
+		if (mtr_launch_gate (ga, st)) { plan_abort (e, st); return fail (MTR_ERR_HIP, "k_gate launch"); }
 		{
 			PlanSlot& ps = e->plan_slot[e->plan_cur];                 // k_gate is the plan's last reader
 			HIPCHK (hipEventRecord (ps.done, st));
