@@ -31,7 +31,7 @@
 //
 // The launch covers whole 50 ms tiles [0, n_main tiles per lane) of a call that starts on a fragment boundary; what is
 // left of the call (less than one tile, or a stream that ends within 48 frames of its stride) goes to k_kwtp16 in the
-// same stream order (mtr_engine.hip).  Σ y² per tile leaves through tile_power exactly as from k_kwtp16, so k_gate does
+// same stream order (mtr_engine.hip).  A tile need not be a whole number of steps (44.1 / 88.2 kHz): see ALIGNED below.  Σ y² per tile leaves through tile_power exactly as from k_kwtp16, so k_gate does
 // not know which kernel ran.
 #include <hip/hip_runtime.h>
 
@@ -154,7 +154,9 @@ __device__ __forceinline__ void lo_second (uint32_t& lw, uint32_t hw, float x1)
 	asm ("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "v"(x1));
 }
 
-template <bool EBU>
+// ALIGNED: the tile (a 50 ms fragment) is a whole number of steps — 48, 96, 192, 32 kHz; otherwise (44.1, 88.2 kHz: 2205, 4410 frames)
+// the step in which a tile ends runs the recurrence frame by frame, with the reference's end-of-fragment actions at the exact frame.
+template <bool EBU, bool ALIGNED>
 __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 {
 	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem_[];
@@ -173,7 +175,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	const int64_t F0 = (int64_t) p0 * a.tile_frames;
 	const v2f* const src = reinterpret_cast<const v2f*> (a.audio) + (size_t) s * a.stride;
 	mtr_stream_state* const st = a.state + s;
-	const int n_steps = (int) (a.n_main * (a.tile_frames / R));
+	const int n_steps = (int) (((uint64_t) a.n_main * a.tile_frames + R - 1) / R);   // (ALIGNED: n_main tiles of spt steps)
 	const int spt = (int) (a.tile_frames / R);
 
 	KCoef kc;
@@ -187,30 +189,32 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 
 	// ---- the stream: four register buffers of 16 frames, loaded three steps ahead ------------------------------------------
 	const bool warm = EBU && q > 0;
-	const float4* lp = reinterpret_cast<const float4*> (src + F0 - (warm ? (int64_t) a.warm_steps * R : 0));
+	typedef float f4v_ __attribute__ ((ext_vector_type (4)));
+	typedef f4v_ float4_a8 __attribute__ ((aligned (8)));              // (a segment may start on any frame: 8-byte alignment is all there is)
+	const float4_a8* lp = reinterpret_cast<const float4_a8*> (src + F0 - (warm ? (int64_t) a.warm_steps * R : 0));
 	v2f xq[4][R];
 #ifdef MTR_SEG_DBG_COOP
 	// (timing probe only, WRONG DATA: instruction i reads whole lines — lanes 8 k .. 8 k + 7 the eight chunks of the line of
 	// lane 8 i + k — to price the address pipeline's share of a step: 64 line fragments per instruction against 8 lines)
-	const float4* lpc[R / 2];
+	const float4_a8* lpc[R / 2];
 #pragma unroll
 	for (int i = 0; i < R / 2; ++i) {
 		const int from = 8 * i + (lane >> 3);
 		const uint64_t pv = reinterpret_cast<uint64_t> (lp);
 		const uint32_t lo = (uint32_t) __shfl ((int) (uint32_t) pv, from), hi = (uint32_t) __shfl ((int) (uint32_t) (pv >> 32), from);
-		lpc[i] = reinterpret_cast<const float4*> (((uint64_t) hi << 32) | lo) + (lane & 7);
+		lpc[i] = reinterpret_cast<const float4_a8*> (((uint64_t) hi << 32) | lo) + (lane & 7);
 	}
-	const float4* const lp0 = lp;
+	const float4_a8* const lp0 = lp;
 	auto load = [&]<int B> () __attribute__ ((always_inline)) {
 		const int64_t d = lp - lp0;
 #pragma unroll
-		for (int i = 0; i < R / 2; ++i) { const float4 v = lpc[i][d]; xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w}; }
+		for (int i = 0; i < R / 2; ++i) { const f4v_ v = lpc[i][d]; xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w}; }
 	};
 #else
 	auto load = [&]<int B> () __attribute__ ((always_inline)) {
 #pragma unroll
 		for (int i = 0; i < R / 2; ++i) {
-			const float4 v = lp[i];      // (plain loads: the eight 16-byte reads of a lane's line merge in the L1 — as nt loads they go to the L2 one by one: 17.4 ms)
+			const f4v_ v = lp[i];        // (plain loads: the eight 16-byte reads of a lane's line merge in the L1 — as nt loads they go to the L2 one by one: 17.4 ms)
 			xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w};
 		}
 	};
@@ -417,7 +421,8 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 #ifdef MTR_SEG_PROF
 	unsigned long long sprof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
-	auto step = [&]<int U, bool PROD> () __attribute__ ((always_inline)) {
+	// KW: the recurrence rides in this step's schedule (EBU; not in the step of an unaligned tile's end)
+	auto step = [&]<int U, bool PROD, bool KW> () __attribute__ ((always_inline)) {
 		v2f (&x)[R] = xq[U];
 		SPROF_NOW (c0_);
 		// phase 0 = |x[n - 24]| for the frames of this call: everything but its last 24 frames
@@ -465,7 +470,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		kw.x[0] = ks.z2; kw.x[1] = ks.z1;
 		constexpr int KGAP = 6;                                     // operations of the recurrence behind the MFMAs of one chunk
 		auto kseq = [&]<int I> () __attribute__ ((always_inline)) {
-			if constexpr (EBU && I < KOPS) kopx<kseq_tab.op[I]> (kc, ks, kw, x, kseq_tab.frame[I]);
+			if constexpr (KW && I < KOPS) kopx<kseq_tab.op[I]> (kc, ks, kw, x, kseq_tab.frame[I]);
 		};
 		auto chunk = [&]<int BC> (m16::BFrag& Bc, m16::BFrag& Bn, m16::f4 (&yc)[3], m16::f4 (&yp)[3]) __attribute__ ((always_inline)) {
 			constexpr int PB = (BC + 7) & 7;
@@ -521,7 +526,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		chunk.template operator()<7> (B1, B0, y1, y0);
 		SPROF_NOW (c4_); SPROF_ADD (3, c4_ - c3_);
 		// the rest of the recurrence's sequence: one packed block
-		if (EBU) {
+		if (KW) {
 			[&]<int... Is> (std::integer_sequence<int, Is...>) __attribute__ ((always_inline)) {
 				(kseq.template operator()<8 * KGAP + Is> (), ...);
 			} (std::make_integer_sequence<int, KOPS - 8 * KGAP>{});
@@ -530,7 +535,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		asm volatile ("" : "+v"(nl), "+v"(nr));
 		ml = nl; mr = nr;
 		++j;
-		if (EBU && --tile_left == 0) {
+		if (KW && ALIGNED && --tile_left == 0) {
 			if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
 			ks.sj = 0;
 			ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);   // ebu_r128_proc.cc:331-334
@@ -539,19 +544,52 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		SPROF_NOW (c5_); SPROF_ADD (4, c5_ - c4_); SPROF_ADD (5, c5_ - c0_); SPROF_ADD (6, 1);
 	};
 
+	// An unaligned tile ends inside a step (the same step and frame for all lanes: every lane starts on a tile boundary).  That
+	// step's recurrence runs here, frame by frame, behind the step's products: Σ y² closes at the exact frame, the states are
+	// scrubbed there (ebu_r128_proc.cc:331-334), and the lane's last tile end is where its filter state is final — the frames of
+	// the step behind it belong to the next segment (or to k_kwtp16's tail of the call).
+	int frames_left = (int) a.tile_frames;                            // of the open tile, at the start of the next step
+	uint32_t tiles_done = 0;
+	KState kfin = ks;
+	auto kslow = [&]<int U> () __attribute__ ((always_inline)) {
+		const v2f (&x)[R] = xq[U];
+		const int k = frames_left;                                    // 1 .. 16: frames of this step that belong to the open tile
+		auto tile_end = [&] () __attribute__ ((always_inline)) {
+			if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
+			ks.sj = 0;
+			ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);
+			++tile;
+			if (++tiles_done == a.n_main) kfin = ks;
+		};
+#pragma unroll
+		for (int n = 0; n < R; ++n) {
+			if (n == k) tile_end ();
+			kstep (kc, ks, x[n]);
+		}
+		if (k == R) tile_end ();
+		frames_left = (int) a.tile_frames - (R - k);
+	};
+	auto do_step = [&]<int U, bool PROD> () __attribute__ ((always_inline)) {
+		if constexpr (!EBU || ALIGNED) step.template operator()<U, PROD, EBU> ();
+		else {
+			if (frames_left > R) { step.template operator()<U, PROD, true> (); frames_left -= R; }
+			else { step.template operator()<U, PROD, false> (); kslow.template operator()<U> (); }
+		}
+	};
+
 	// (the first three loads above were steps 0..2; step 0 has no products in front of it)
 	lp -= R / 2;                                                      // `step` advances before it loads
 	maxabs.template operator()<0> ();
-	step.template operator()<0, false> ();
+	do_step.template operator()<0, false> ();
 	while (j + 4 <= n_steps) {
-		step.template operator()<1, true> ();
-		step.template operator()<2, true> ();
-		step.template operator()<3, true> ();
-		step.template operator()<0, true> ();
+		do_step.template operator()<1, true> ();
+		do_step.template operator()<2, true> ();
+		do_step.template operator()<3, true> ();
+		do_step.template operator()<0, true> ();
 	}
-	if (j < n_steps) step.template operator()<1, true> ();
-	if (j < n_steps) step.template operator()<2, true> ();
-	if (j < n_steps) step.template operator()<3, true> ();
+	if (j < n_steps) do_step.template operator()<1, true> ();
+	if (j < n_steps) do_step.template operator()<2, true> ();
+	if (j < n_steps) do_step.template operator()<3, true> ();
 	switch (n_steps & 3) {                                           // the products of the last step
 	case 0:  products.template operator()<0> (); break;
 	case 1:  products.template operator()<1> (); break;
@@ -567,8 +605,9 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		atomicMax (&st->tp_call[0], __float_as_uint (fmaxf (pk0.x, pkf.x)));
 		atomicMax (&st->tp_call[1], __float_as_uint (fmaxf (pk0.y, pkf.y)));
 		if (EBU && q == a.n_segs - 1) {
-			st->kz[0] = ks.z1.x; st->kz[1] = ks.z1.y; st->kz[2] = ks.z2.x; st->kz[3] = ks.z2.y;
-			st->kz[4] = ks.z3.x; st->kz[5] = ks.z3.y; st->kz[6] = ks.z4.x; st->kz[7] = ks.z4.y;
+			const KState& kf = ALIGNED ? ks : kfin;                       // (unaligned: the state at the lane's last tile end)
+			st->kz[0] = kf.z1.x; st->kz[1] = kf.z1.y; st->kz[2] = kf.z2.x; st->kz[3] = kf.z2.y;
+			st->kz[4] = kf.z3.x; st->kz[5] = kf.z3.y; st->kz[6] = kf.z4.x; st->kz[7] = kf.z4.y;
 		}
 	}
 }
@@ -587,7 +626,9 @@ extern "C" int mtr_debug_seg_prof (unsigned long long* out)
 int mtr_launch_seg (bool ebu, const mtr_seg_args& a, uint32_t n_waves, void* stream)
 {
 	hipStream_t st = (hipStream_t) stream;
-	if (ebu) hipLaunchKernelGGL ((k_seg<true>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);
-	else     hipLaunchKernelGGL ((k_seg<false>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);
+	const bool aligned = a.tile_frames % R == 0;
+	if (!ebu)         hipLaunchKernelGGL ((k_seg<false, false>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);    // (no tiles without Σ y²)
+	else if (aligned) hipLaunchKernelGGL ((k_seg<true, true>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);
+	else              hipLaunchKernelGGL ((k_seg<true, false>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }

@@ -62,11 +62,13 @@ def _check_ebu(got, ref, s, tag):
     assert np.abs(got["hist"][1][s] - ref["hist_S"]).sum() // 2 <= 2, (tag, s)
 
 
-@pytest.mark.parametrize("fs", [48000.0, 96000.0, 32000.0])
+@pytest.mark.parametrize("fs", [48000.0, 96000.0, 32000.0, 44100.0, 88200.0])
 @pytest.mark.parametrize("segs", [1, 2, 5])
 def test_seg_matches_oracle(M, oracle, fs, segs):
     """Whole-fragment calls, calls with a tail behind the last fragment, several calls in a row (the K-filter state and
-    the interpolator's history cross the call boundary), segments of unequal length (the shorter ones start a tile early)."""
+    the interpolator's history cross the call boundary), segments of unequal length (the shorter ones start a tile early).
+    44.1 and 88.2 kHz: fragments of 2205 / 4410 frames are not whole 16-frame steps — a tile ends inside a step, segments
+    start on odd frames, and a call that is exactly N fragments long leaves its last fragment to the tail kernel."""
     fragm = int(fs) // 20
     calls = [fragm * 37, fragm * 30 + 777, fragm * 3 - 777, fragm * 26]           # the 2nd call ends inside a fragment ...
     T = sum(calls)
@@ -75,7 +77,8 @@ def test_seg_matches_oracle(M, oracle, fs, segs):
     got = _run(M, x, calls, fs, tune_segments=segs, tune_layout=7)
     assert got["layout"] == 7
     # ... so the 3rd starts inside one and runs layout 6; calls 1, 2 and 4 start on a boundary
-    assert got["seg"][0] == 3 and got["seg"][1] == fragm * (37 + 30 + 26), got["seg"]
+    whole = fragm % 16 == 0                                                        # (otherwise: 15 frames of read-ahead must exist behind the last tile)
+    assert got["seg"][0] == 3 and got["seg"][1] == fragm * (37 + 30 + 26 - (0 if whole else 2)), got["seg"]
     for s in range(S):
         _check_ebu(got, oracle.ebu(x[s], fs, fragm, want_frag=True), s, (fs, segs))
         assert _rel(got["tp"][s], oracle.tp(x[s], fs, 8192)).max() <= TP_RTOL, (s, got["tp"][s])
@@ -86,14 +89,15 @@ def test_seg_matches_oracle(M, oracle, fs, segs):
 
 
 def test_seg_not_taken_where_it_does_not_fit(M, oracle):
-    """44.1 kHz fragments are 2205 frames (not a multiple of 16), a call that starts inside a fragment, an odd stride, a
-    small batch without tune_segments, pruning: layout 6 serves all of them, and the results are the usual ones."""
+    """A call that starts inside a fragment, an odd stride, a small batch without tune_segments, pruning: layout 6 serves all
+    of them, and the results are the usual ones.  (44.1 kHz — 2205-frame fragments, not a multiple of 16 — is k_seg's too.)"""
     T = 44100 * 4
     x = np.stack([tri_noise(T, 30 + s, 0.5, period=50000) for s in range(3)])
     got = _run(M, x, [T], 44100.0, tune_segments=4, tune_layout=7)
-    assert got["seg"][0] == 0
+    assert got["seg"] == (1, T - 2205), got["seg"]                              # the call is 80 fragments: the last one is the tail's
     for s in range(3):
         _check_ebu(got, oracle.ebu(x[s], 44100.0, 2205, want_frag=True), s, "44k1")
+        assert _rel(got["tp"][s], oracle.tp(x[s], 44100.0, 8192)).max() <= TP_RTOL
     T = 48000 * 4
     x = np.stack([tri_noise(T, 60 + s, 0.5, period=50000) for s in range(3)])
     assert _run(M, x, [T])["seg"][0] == 0                                     # three streams do not fill 65536 lanes
@@ -156,6 +160,32 @@ def test_seg_edge_signals(M, oracle):
     assert _rel(got["tp"][0, 1], ref["tp"][0, 1]) <= TP_RTOL and _rel(got["tp"][1, 0], ref["tp"][1, 0]) <= TP_RTOL
     # (the NaN's own channel: both layouts drop the outputs of the 16-frame columns the NaN reaches)
     assert _rel(got["tp"][1, 1], ref["tp"][1, 1]) <= 1e-2
+
+
+def test_seg_unaligned_tiles_scrub_at_the_exact_frame(M):
+    """44.1 kHz: a fragment ends inside a 16-frame step.  The reference zeroes non-finite filter states at the fragment's end
+    (ebu_r128_proc.cc:331-334): a NaN / Inf sample poisons its own fragment's power and not the next one — at the exact frame,
+    as the wave-per-segment kernel does it; and the filter state handed to the tail of the call is the one at the last whole
+    fragment's end (the frames of the step behind it are the tail's)."""
+    import _signals as sig
+    fs, fragm = 44100.0, 2205
+    T = fragm * 40 + 1000
+    n = sig.lcg_noise(T, 5, 0.25).astype(np.float32)
+    bad = np.stack([n, n.copy(), n.copy(), n.copy()])
+    bad[1, fragm * 7 + 100, 0] = np.nan                        # inside a fragment
+    bad[2, fragm * 9 - 1, 1] = np.inf                          # a fragment's last frame
+    bad[3, fragm * 11, 0] = np.nan                             # a fragment's first frame
+    ref = _run(M, bad, [T], fs, tune_layout=6)
+    assert ref["seg"][0] == 0
+    for segs in (1, 3):
+        got = _run(M, bad, [T], fs, tune_segments=segs, tune_layout=7)
+        assert got["seg"] == (1, fragm * 40), got["seg"]
+        bad_g, bad_r = ~np.isfinite(got["frag"]), ~np.isfinite(ref["frag"])
+        assert np.array_equal(bad_g, bad_r), (segs, np.argwhere(bad_g != bad_r))
+        assert bad_r[1:].sum() >= 3 and bad_r.sum() <= 8
+        assert np.allclose(got["frag"][~bad_g], ref["frag"][~bad_r], rtol=2e-5)
+        again = _run(M, bad, [T], fs, tune_segments=segs, tune_layout=7)
+        assert np.array_equal(got["frag"], again["frag"], equal_nan=True) and np.array_equal(got["tp"], again["tp"], equal_nan=True)
 
 
 def test_seg_truepeak_only_and_ragged_batch(M, oracle):
