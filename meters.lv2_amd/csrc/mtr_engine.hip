@@ -604,11 +604,10 @@ static SegPlan seg_plan (const mtr_engine* e, const float* d_audio, uint64_t N, 
 	if (!e->seg_ok || e->layout != 6 || e->cfg.n_channels != 2) return sp;
 	if (e->fragm < 4 * MTR_SEG_STEP || e->frcnt != e->fragm) return sp;
 	if (reinterpret_cast<uintptr_t> (d_audio) & 7) return sp;
-	// a tile that is not a whole number of steps (44.1 / 88.2 kHz) lets a lane read up to 15 frames past its last tile:
-	// they must be frames of this call (k_kwtp16's tail owns them), and a segment then starts on any frame — 8-byte loads'
-	// alignment; with whole steps the 16-byte alignment of every segment start is kept (even stride, 16-byte base)
+	// (a segment may start on any frame — odd strides, 2205-frame fragments: the kernel's loads only assume a frame's 8 bytes)
+	// A tile that is not a whole number of steps (44.1 / 88.2 kHz) lets a lane read up to 15 frames past its last tile:
+	// they must be frames of this call (k_kwtp16's tail owns them).
 	const bool whole = e->fragm % MTR_SEG_STEP == 0;
-	if (whole && ((stride & 1) || (reinterpret_cast<uintptr_t> (d_audio) & 15))) return sp;
 	uint64_t tiles = N / e->fragm;
 	if (!whole && tiles && tiles * e->fragm + MTR_SEG_STEP > N) --tiles;
 	if (tiles == 0 || tiles > 0x7fffffffull / (e->fragm / MTR_SEG_STEP + 1)) return sp;

@@ -89,8 +89,8 @@ def test_seg_matches_oracle(M, oracle, fs, segs):
 
 
 def test_seg_not_taken_where_it_does_not_fit(M, oracle):
-    """A call that starts inside a fragment, an odd stride, a small batch without tune_segments, pruning: layout 6 serves all
-    of them, and the results are the usual ones.  (44.1 kHz — 2205-frame fragments, not a multiple of 16 — is k_seg's too.)"""
+    """A call that starts inside a fragment, a small batch without tune_segments, pruning: layout 6 serves them, and the results
+    are the usual ones.  (44.1 kHz — 2205-frame fragments, not a multiple of 16 — and odd strides are k_seg's too.)"""
     T = 44100 * 4
     x = np.stack([tri_noise(T, 30 + s, 0.5, period=50000) for s in range(3)])
     got = _run(M, x, [T], 44100.0, tune_segments=4, tune_layout=7)
@@ -110,12 +110,14 @@ def test_seg_not_taken_where_it_does_not_fit(M, oracle):
         buf = torch.zeros(3 * (T + 1) * 2 + 2, dtype=torch.float32, device="cuda")
         view = buf[: 3 * (T + 1) * 2].view(3, T + 1, 2)
         view[:, :T] = torch.from_numpy(x).cuda()
-        e.process_device(buf.data_ptr(), T, T + 1)                           # odd stride: streams 1 and 3 sit on 8 bytes
+        e.process_device(buf.data_ptr(), T, T + 1)                           # odd stride: streams 1 and 3 sit on 8 bytes — fine
         torch.cuda.synchronize()
-        assert e.seg_stats()[0] == 0
+        assert e.seg_stats() == (1, T)
         tp = e.truepeak()
+        o9 = e.out9()
     for s in range(3):
         assert _rel(tp[s], oracle.tp(x[s], 48000.0, 8192)).max() <= TP_RTOL
+        assert np.allclose(o9[s, :4], oracle.ebu(x[s], 48000.0, 2400)["out9"][:4], atol=1e-3)
 
 
 def test_seg_edge_signals(M, oracle):
