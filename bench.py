@@ -382,9 +382,9 @@ def main():
             peaks = eng.truepeak()
             o9 = eng.out9()
 
-            def timed(eS, eT, emeters, steps=3, **kw):
+            def timed(eS, eT, emeters, steps=3, efs=None, **kw):
                 """ms per launch of the fused / gate / bank kernels for eS streams x eT frames of the same buffer."""
-                with M.Engine(eS, fs, emeters, device=local, **kw) as x:
+                with M.Engine(eS, efs or fs, emeters, device=local, **kw) as x:
                     if emeters & M.METER_EBU:
                         x.integr_start()
                     x.process_device(buf.data_ptr(), eT, eT, stream)
@@ -493,11 +493,15 @@ def main():
             f, _, _, w, k = timed(S, T, M.METER_TRUEPEAK, steps=5)
             cfgs["true peak only, 8192 streams x 10 s"] = {"kernel": k["kernel"], "kernel_ms": f, "wall_ms": w, "frac": frac(S, T, f),
                                                            "bound": "SIMD issue (MFMA) under the power cap"}
+            T44 = 441000                                          # 10 s at 44.1 kHz: 200 fragments of 2205 frames, which are not whole 16-frame steps
+            f, g, _, w, k = timed(S, T44, meters, steps=5, efs=44100.0)
+            cfgs["EBU R128 + true peak at 44.1 kHz, 8192 streams x 10 s"] = {"kernel": k["kernel"], "kernel_ms": f, "gate_ms": g, "wall_ms": w,
+                                                                           "frac": frac(S, T44, f), "bound": "SIMD issue under the power cap"}
             _, _, bk, w, _ = timed(S, T, M.METER_TPBALLIST, steps=2)
             cfgs["true-peak ballistics (TruePeakdsp::process), 8192 streams x 10 s"] = {
                 "kernel": "k_tpb", "kernel_ms": bk, "wall_ms": w, "frac": frac(S, T, bk),
-                "bound": "latency of the serial attack / release chain: one lane per (stream, channel) walks 4 x 480 000 dependent steps; 16 384 chains "
-                         "occupy a quarter of the chip's lanes (DESIGN.md 3.5)"}
+                "bound": "the busiest SIMD pair of a workgroup (four blocks of matrix-pipe products + per-frame max-affine maps on three SIMDs beside "
+                         "the serial chains: 3 dependent operations per frame and channel; DESIGN.md 3.5)"}
             extra["configs"] = cfgs
             try:
                 from _lv2host import Host
