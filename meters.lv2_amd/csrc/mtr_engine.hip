@@ -77,7 +77,8 @@ struct Plan {
 	uint32_t frcnt_in = 0;      // frames left in the open fragment when the call starts
 	uint32_t frcnt_out = 0;
 	uint32_t n_tiles = 0, n_frag = 0, n_segs = 0, tail_tile = 0, buf_slots = 0, kw_slots = 0;
-	uint32_t body_tiles = 0;    // whole-fragment tiles in front (the lane = segment kernel's part of the call), 0 = none
+	uint32_t body_tiles = 0;    // whole-fragment tiles (the lane = segment kernel's part of the call), 0 = none
+	uint32_t head_tiles = 0;    // ... and the tiles in front of them (the rest of a fragment the call started in)
 	bool     valid = false;
 };
 
@@ -106,6 +107,7 @@ struct mtr_engine {
 	const uint32_t*  tile_start = nullptr;   // into plan_slot[plan_cur].dev
 	const uint32_t*  seg_tile = nullptr;
 	const uint32_t*  frag_tile = nullptr;
+	const uint32_t*  head_seg = nullptr;     // {0, first tile of the k_seg body}: the one segment of the k_kwtp16 launch in front of it (if any)
 	const uint32_t*  tail_seg = nullptr;     // {first tile behind the k_seg body, n_tiles}: the one segment of the k_kwtp16 launch that finishes such a call
 	// n_streams = 1 host path (the shape of an LV2 run ()): own stream, page-locked staging, and ONE synchronisation per
 	// block — the state (and the bank's levels) come back with the same wait and serve the result getters
@@ -588,11 +590,12 @@ int mtr_engine_spectr_reset_peak (mtr_engine* e)
 // n_segs segments per stream of base (+ 1 for the first rem) tiles; every lane walks n_main of them.
 struct SegPlan {
 	bool     use = false;
+	uint32_t head = 0;          // frames of the call in front of the first whole fragment (the rest of the open one)
 	uint32_t tiles = 0, n_segs = 0, base = 0, rem = 0, n_main = 0, warm_steps = 0;
 };
 
-// Does this call go through k_seg?  It must start on a fragment boundary with 16-frame-aligned fragments and 16-byte
-// aligned streams, and it must be a BATCH: the kernel's unit of parallelism is a lane, so it needs ~64 x the units of
+// Does this call go through k_seg?  It must hold at least one whole fragment behind the one it may start in, and it must be
+// a BATCH: the kernel's unit of parallelism is a lane, so it needs ~64 x the units of
 // k_kwtp16 to fill the chip.  The number of segments per stream is the one that minimises the modelled time — rounds of
 // resident waves x steps per wave, a warm-up step (K-filter only) at 0.3 of a full one — and the call takes this path
 // when that beats the model of k_kwtp16 (1.2 x the time per frame when both fill the machine, measured: 11.7 vs 9.75 ms,
@@ -602,15 +605,20 @@ static SegPlan seg_plan (const mtr_engine* e, const float* d_audio, uint64_t N, 
 	SegPlan sp;
 	const bool ebu = e->cfg.meters & MTR_METER_EBU;
 	if (!e->seg_ok || e->layout != 6 || e->cfg.n_channels != 2) return sp;
-	if (e->fragm < 4 * MTR_SEG_STEP || e->frcnt != e->fragm) return sp;
+	if (e->fragm < 4 * MTR_SEG_STEP) return sp;
 	if (reinterpret_cast<uintptr_t> (d_audio) & 7) return sp;
-	// (a segment may start on any frame — odd strides, 2205-frame fragments: the kernel's loads only assume a frame's 8 bytes)
-	// A tile that is not a whole number of steps (44.1 / 88.2 kHz) lets a lane read up to 15 frames past its last tile:
-	// they must be frames of this call (k_kwtp16's tail owns them).
+	// (a segment may start on any frame — odd strides, 2205-frame fragments, a call that starts inside a fragment: the kernel's
+	// loads only assume a frame's 8 bytes.)  The rest of an open fragment in front (`head`) and what is left behind the last whole
+	// fragment go to k_kwtp16, in stream order.  A tile that is not a whole number of steps (44.1 / 88.2 kHz) lets a lane read up
+	// to 15 frames past its last tile: they must be frames of this call (the tail's).
+	const uint64_t head = e->frcnt != e->fragm ? e->frcnt : 0;
+	if (head >= N) return sp;
+	const uint64_t Nb = N - head;
 	const bool whole = e->fragm % MTR_SEG_STEP == 0;
-	uint64_t tiles = N / e->fragm;
-	if (!whole && tiles && tiles * e->fragm + MTR_SEG_STEP > N) --tiles;
+	uint64_t tiles = Nb / e->fragm;
+	if (!whole && tiles && tiles * e->fragm + MTR_SEG_STEP > Nb) --tiles;
 	if (tiles == 0 || tiles > 0x7fffffffull / (e->fragm / MTR_SEG_STEP + 1)) return sp;
+	sp.head = (uint32_t) head;
 	const double spt = (double) e->fragm / MTR_SEG_STEP;
 	const uint32_t warm_steps = ebu ? ((uint32_t) std::ceil (MTR_SEG_WARM_SEC * e->cfg.sample_rate / (float) MTR_SEG_STEP) + 3) / 4 * 4 : 0;
 	const uint32_t warm_tiles = (warm_steps * MTR_SEG_STEP + e->fragm - 1) / e->fragm;
@@ -643,9 +651,10 @@ static void plan_abort (mtr_engine* e, hipStream_t st)
 	e->plan.valid = false;
 }
 
-// Tiling plan for a call of n_frames starting with `frcnt` frames left in the open fragment.  body_tiles > 0: the call
-// starts on a fragment boundary and its first body_tiles tiles are whole fragments (k_seg's part), whatever their length.
-static int build_plan (mtr_engine* e, uint64_t N, uint32_t body_tiles, hipStream_t st)
+// Tiling plan for a call of n_frames starting with `frcnt` frames left in the open fragment.  body_tiles > 0: behind the
+// `head` frames that finish the open fragment (0 if the call starts on a boundary) body_tiles tiles are whole fragments
+// (k_seg's part), whatever their length.
+static int build_plan (mtr_engine* e, uint64_t N, uint32_t head, uint32_t body_tiles, hipStream_t st)
 {
 	Plan& pl = e->plan;
 	if (pl.valid && pl.n_frames == N && pl.frcnt_in == e->frcnt && pl.body_tiles == body_tiles) return MTR_OK;
@@ -656,9 +665,13 @@ static int build_plan (mtr_engine* e, uint64_t N, uint32_t body_tiles, hipStream
 	ts.reserve ((size_t) (N / LT + N / e->fragm + 4));
 	uint64_t pos = 0;
 	uint32_t left = e->frcnt;
+	uint32_t head_tiles = 0, body_done = 0;
 	ft.push_back (0);
 	while (pos < N) {
-		const uint32_t piece = ts.size () < body_tiles ? e->fragm : (uint32_t) std::min<uint64_t> (std::min<uint64_t> (LT, left), N - pos);
+		const bool body = body_done < body_tiles && pos >= head;
+		if (body && body_done == 0) head_tiles = (uint32_t) ts.size ();
+		body_done += body;
+		const uint32_t piece = body ? e->fragm : (uint32_t) std::min<uint64_t> (std::min<uint64_t> (LT, left), N - pos);
 		ts.push_back ((uint32_t) pos);
 		pos += piece;
 		left -= piece;
@@ -683,7 +696,7 @@ static int build_plan (mtr_engine* e, uint64_t N, uint32_t body_tiles, hipStream
 	}
 	const uint64_t max_segs = std::max<uint64_t> (1, N / std::max<uint64_t> (min_seg_frames, 1));
 	n_segs = (uint32_t) std::min<uint64_t> (n_segs, max_segs);
-	if (body_tiles) n_segs = 1;                                 // k_kwtp16 only finishes such a call: one segment (tail_seg)
+	if (body_tiles) n_segs = 1;                                 // k_kwtp16 only starts / finishes such a call: one segment each (head_seg, tail_seg)
 	n_segs = std::max<uint32_t> (1, std::min<uint32_t> (n_segs, n_tiles));
 	std::vector<uint32_t> sg (n_segs + 1);
 	for (uint32_t q = 0; q <= n_segs; ++q) sg[q] = (uint32_t) ((uint64_t) q * n_tiles / n_segs);
@@ -699,26 +712,28 @@ static int build_plan (mtr_engine* e, uint64_t N, uint32_t body_tiles, hipStream
 	const int slot = (e->plan_cur + 1) % PLAN_SLOTS;
 	PlanSlot& ps = e->plan_slot[slot];
 	if (ps.pending) { HIPCHK (hipEventSynchronize (ps.done)); ps.pending = false; }
-	const uint32_t tseg[2] = { body_tiles, n_tiles };
-	const size_t words = ts.size () + sg.size () + ft.size () + 2;
+	const uint32_t tseg[4] = { 0, head_tiles, head_tiles + body_tiles, n_tiles };
+	const size_t words = ts.size () + sg.size () + ft.size () + 4;
 	if (ps.dev.reserve (std::max<size_t> (words, 256)) || ps.pin.reserve (std::max<size_t> (words, 256))) return fail (MTR_ERR_NOMEM, "plan slot");
 	if (!ps.done) HIPCHK (hipEventCreateWithFlags (&ps.done, hipEventDisableTiming));
 	memcpy (ps.pin.p, ts.data (), ts.size () * 4);
 	memcpy (ps.pin.p + ts.size (), sg.data (), sg.size () * 4);
 	memcpy (ps.pin.p + ts.size () + sg.size (), ft.data (), ft.size () * 4);
-	memcpy (ps.pin.p + ts.size () + sg.size () + ft.size (), tseg, 8);
+	memcpy (ps.pin.p + ts.size () + sg.size () + ft.size (), tseg, 16);
 	HIPCHK (hipMemcpyAsync (ps.dev.p, ps.pin.p, words * 4, hipMemcpyHostToDevice, st));
 	// (the slot is busy from here on: its `done` event is recorded behind the plan's last reader, k_gate — or by plan_abort ()
 	// if a launch behind this copy fails, so that the slot is never handed out again under a pending upload: ADVICE r2.
 	// One hipEventRecord per call, not two: it is 2-3 us of an LV2 run ().)
 	e->plan_cur = slot;
 	e->tile_start = ps.dev.p; e->seg_tile = ps.dev.p + ts.size (); e->frag_tile = ps.dev.p + ts.size () + sg.size ();
-	e->tail_seg = e->frag_tile + ft.size ();
+	e->head_seg = e->frag_tile + ft.size ();
+	e->tail_seg = e->head_seg + 2;
 
 	pl.n_frames = N; pl.frcnt_in = e->frcnt; pl.frcnt_out = left;
-	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail; pl.body_tiles = body_tiles;
+	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail; pl.body_tiles = body_tiles; pl.head_tiles = head_tiles;
 	uint32_t maxlen = n_segs > 1 ? LT : 0;                      // warm-up tiles are full tiles
-	for (uint32_t j = body_tiles; j < n_tiles; ++j) maxlen = std::max (maxlen, ts[j + 1] - ts[j]);
+	for (uint32_t j = 0; j < n_tiles; ++j)
+		if (j < head_tiles || j >= head_tiles + body_tiles) maxlen = std::max (maxlen, ts[j + 1] - ts[j]);
 	// + look-ahead frames of the FIR register tile + 4 slots for the carried K-filter state (layout 3)
 	pl.buf_slots = (maxlen + 48 + 13 + 4 + 127) / 128 * 128;
 	pl.kw_slots = (maxlen + 1 + 127) / 128 * 128;               // k_kw: the tile + one frame of alignment slack
@@ -771,7 +786,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 
 	if (ebu || tp) {
 		const SegPlan sp = seg_plan (e, d_audio, n_frames, stride);
-		int rc = build_plan (e, n_frames, sp.use ? sp.tiles : 0, st);
+		int rc = build_plan (e, n_frames, sp.use ? sp.head : 0, sp.use ? sp.tiles : 0, st);
 		if (rc) return rc;
 		const Plan& pl = e->plan;
 		mtr_fused_args fa;
@@ -793,22 +808,30 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.prune_stats = e->prune_cnt.p;
 		int lrc = 0;
 		if (sp.use) {
-			// the batch path: whole fragments through k_seg, what is left of the call (less than a fragment) through
-			// k_kwtp16 behind it, as ONE segment that picks the K-filter state up where k_seg's last segment left it
+			// the batch path: whole fragments through k_seg; the rest of an open fragment in front of them and what is left of
+			// the call behind them (less than a fragment each) through k_kwtp16, each as ONE segment that picks the K-filter
+			// state up where its predecessor in the stream left it
+			const uint32_t* const all_seg = fa.seg_tile;
+			if (pl.head_tiles) {
+				fa.seg_tile = e->head_seg; fa.n_segs = 1;
+				lrc = mtr_launch_kwtp16 (e->run, ebu, fa, S, st);
+			}
 			mtr_seg_args sa;
 			sa.audio = d_audio; sa.stride = stride; sa.hist = fa.hist; sa.state = e->state.p; sa.tile_power = e->tile_power.p;
+			sa.head = sp.head; sa.tile0 = pl.head_tiles;
 			sa.mfma_a = e->m16_a.p;
 			sa.n_streams = S; sa.n_segs = sp.n_segs; sa.n_tiles = pl.n_tiles; sa.tile_frames = e->fragm;
 			sa.seg_base = sp.base; sa.seg_rem = sp.rem; sa.n_main = sp.n_main; sa.warm_steps = sp.warm_steps;
-			sa.p0_end = (int64_t) n_frames - 24;
+			sa.p0_end = (int64_t) n_frames - 24 - (int64_t) sp.head;
 			sa.a0 = fa.a0; sa.a1 = fa.a1; sa.a2 = fa.a2; sa.b1 = fa.b1; sa.b2 = fa.b2; sa.c3 = fa.c3; sa.c4 = fa.c4;
 			sa.gain_l = fa.gain_l; sa.gain_r = fa.gain_r;
 			const uint64_t units = (uint64_t) S * sp.n_segs;
-			lrc = mtr_launch_seg (ebu, sa, (uint32_t) ((units + 63) / 64), st);
-			if (!lrc && pl.n_tiles > sp.tiles) {
+			if (!lrc) lrc = mtr_launch_seg (ebu, sa, (uint32_t) ((units + 63) / 64), st);
+			if (!lrc && pl.n_tiles > pl.head_tiles + sp.tiles) {
 				fa.seg_tile = e->tail_seg; fa.n_segs = 1;
 				lrc = mtr_launch_kwtp16 (e->run, ebu, fa, S, st);
 			}
+			(void) all_seg;
 			e->seg_calls += 1; e->seg_frames += (uint64_t) sp.tiles * e->fragm;
 		} else {
 			lrc = e->layout == 6 ? mtr_launch_kwtp16 (e->run, ebu, fa, S * pl.n_segs, st)

@@ -61,16 +61,18 @@ struct mtr_fused_args {
  * them, starting one tile early where its own segment is the shorter kind. */
 #define MTR_SEG_STEP 16            /* frames per lane and step: one column of the block-Toeplitz product */
 typedef struct mtr_seg_args {
-	const float*    audio;        /* [S][stride][2], 16-byte aligned, stride even */
+	const float*    audio;        /* [S][stride][2]: the call's buffer (8-byte aligned: a segment may start on any frame) */
 	uint64_t        stride;       /* frames */
 	const float*    hist;         /* [S][47][2]: the 47 frames before frame 0 of this call */
+	uint32_t        head;         /* frames of this call in front of the launch's first tile (the rest of a fragment the call started in) */
+	uint32_t        tile0;        /* ... and how many tiles of the plan they are: tile_power index of the launch's first tile */
 	mtr_stream_state* state;      /* [S] */
 	float*          tile_power;   /* [S][n_tiles] */
 	const uint16_t* mfma_a;       /* [12][64][8] hi / lo A fragments (mtr_mfma16_fir.h) */
 	uint32_t        n_streams, n_segs, n_tiles, tile_frames;
 	uint32_t        seg_base, seg_rem, n_main;
 	uint32_t        warm_steps;   /* K-filter warm-up in front of a segment that does not start the call: steps of 16 frames, multiple of 4 */
-	int64_t         p0_end;       /* phase 0 (|x[n - 24]|) of this call covers the frames below n_frames - 24 */
+	int64_t         p0_end;       /* phase 0 (|x[n - 24]|) of this call covers the frames below n_frames - 24: that frame, counted from the first tile */
 	float           a0, a1, a2, b1, b2, c3, c4;
 	float           gain_l, gain_r;
 } mtr_seg_args;

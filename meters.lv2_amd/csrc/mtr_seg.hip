@@ -29,9 +29,9 @@
 //     rest of the recurrence is one packed block per step, software-pipelined over frames;
 //   * loads: lane l reads its own 128 bytes per step (8 x global_load_dwordx4, one cache line), three steps ahead.
 //
-// The launch covers whole 50 ms tiles [0, n_main tiles per lane) of a call that starts on a fragment boundary; what is
-// left of the call (less than one tile, or a stream that ends within 48 frames of its stride) goes to k_kwtp16 in the
-// same stream order (mtr_engine.hip).  A tile need not be a whole number of steps (44.1 / 88.2 kHz): see ALIGNED below.  Σ y² per tile leaves through tile_power exactly as from k_kwtp16, so k_gate does
+// The launch covers the whole 50 ms tiles of a call, n_main per lane; the rest of a fragment the call started in (`head`
+// frames in front of the first tile) and what is left behind the last whole tile go to k_kwtp16 in the same stream order
+// (mtr_engine.hip).  A tile need not be a whole number of steps (44.1 / 88.2 kHz): see ALIGNED below.  Σ y² per tile leaves through tile_power exactly as from k_kwtp16, so k_gate does
 // not know which kernel ran.
 #include <hip/hip_runtime.h>
 
@@ -173,7 +173,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	const uint32_t cq = a.seg_base + (q < a.seg_rem ? 1u : 0u);
 	const uint32_t p0 = fq + cq - a.n_main;                           // first tile it processes (one early where its segment is short)
 	const int64_t F0 = (int64_t) p0 * a.tile_frames;
-	const v2f* const src = reinterpret_cast<const v2f*> (a.audio) + (size_t) s * a.stride;
+	const v2f* const src = reinterpret_cast<const v2f*> (a.audio) + (size_t) s * a.stride + a.head;   // frame 0 = the launch's first tile
 	mtr_stream_state* const st = a.state + s;
 	const int n_steps = (int) (((uint64_t) a.n_main * a.tile_frames + R - 1) / R);   // (ALIGNED: n_main tiles of spt steps)
 	const int spt = (int) (a.tile_frames / R);
@@ -293,7 +293,8 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 #pragma unroll
 			for (int n = 0; n < R; ++n) {
 				const int64_t f = F0 - 48 + R * k + n;
-				px[k][n] = f >= 0 ? src[f] : (f >= -MTR_FIR_HALO ? hst[f + MTR_FIR_HALO] : v2f{0.f, 0.f});
+				const int64_t fc = f + (int64_t) a.head;                     // the call's own frame; in front of it: the history
+				px[k][n] = fc >= 0 ? src[f] : (fc >= -MTR_FIR_HALO ? hst[fc + MTR_FIR_HALO] : v2f{0.f, 0.f});
 			}
 		float ml = 0.f, mr = 0.f;
 #pragma unroll
@@ -303,7 +304,8 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		scl.set (ml); scr.set (mr);
 		split_store (px[0], 1); split_store (px[1], 2); split_store (px[2], 3);
 		if (F0 == 0) {
-			// phase 0 of this call starts with frames -24 .. -1 (the launch starts the call; the call is longer than 48 frames)
+			// phase 0 of the launch's first outputs is frames -24 .. -1: the history of a launch that starts the call, else the
+			// call's own frames in front of it (whose owner, the kernel of the call's head, stops 24 frames short of them)
 #pragma unroll
 			for (int n = 8; n < R; ++n) pk0 = v2f{fmaxf (pk0.x, fabsf (px[1][n].x)), fmaxf (pk0.y, fabsf (px[1][n].y))};
 #pragma unroll
@@ -536,7 +538,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		ml = nl; mr = nr;
 		++j;
 		if (KW && ALIGNED && --tile_left == 0) {
-			if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
+			if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + a.tile0 + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
 			ks.sj = 0;
 			ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);   // ebu_r128_proc.cc:331-334
 			tile_left = spt; ++tile;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		const v2f (&x)[R] = xq[U];
 		const int k = frames_left;                                    // 1 .. 16: frames of this step that belong to the open tile
 		auto tile_end = [&] () __attribute__ ((always_inline)) {
-			if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
+			if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + a.tile0 + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
 			ks.sj = 0;
 			ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);
 			++tile;

@@ -102,7 +102,8 @@ def test_exact_peak_pruning_changes_nothing_but_time(M, oracle):
     res = {}
     for prune in (0, 1):
         for segs in (0, 4):
-            with M.Engine(4, 48000.0, M.METER_EBU | M.METER_TRUEPEAK, tune_prune=prune, tune_segments=segs) as e:
+            # (layout 6 for both: pruning is its feature, and with tune_segments the dense engine would otherwise take k_seg)
+            with M.Engine(4, 48000.0, M.METER_EBU | M.METER_TRUEPEAK, tune_prune=prune, tune_segments=segs, tune_layout=6) as e:
                 e.integr_start()
                 for a, b in ((0, 100000), (100000, T)):          # two calls: history + running state carry over
                     e.process(x[:, a:b])

@@ -76,9 +76,9 @@ def test_seg_matches_oracle(M, oracle, fs, segs):
     x = np.stack([tri_noise(T, 700 + s, 2.0 ** -(s % 3), period=72000) for s in range(S)])
     got = _run(M, x, calls, fs, tune_segments=segs, tune_layout=7)
     assert got["layout"] == 7
-    # ... so the 3rd starts inside one and runs layout 6; calls 1, 2 and 4 start on a boundary
+    # ... so the 3rd starts inside one: the rest of that fragment is the wave-per-segment kernel's, two whole fragments follow
     whole = fragm % 16 == 0                                                        # (otherwise: 15 frames of read-ahead must exist behind the last tile)
-    assert got["seg"][0] == 3 and got["seg"][1] == fragm * (37 + 30 + 26 - (0 if whole else 2)), got["seg"]
+    assert got["seg"][0] == 4 and got["seg"][1] == fragm * (37 + 30 + 2 + 26 - (0 if whole else 3)), got["seg"]
     for s in range(S):
         _check_ebu(got, oracle.ebu(x[s], fs, fragm, want_frag=True), s, (fs, segs))
         assert _rel(got["tp"][s], oracle.tp(x[s], fs, 8192)).max() <= TP_RTOL, (s, got["tp"][s])
@@ -89,8 +89,9 @@ def test_seg_matches_oracle(M, oracle, fs, segs):
 
 
 def test_seg_not_taken_where_it_does_not_fit(M, oracle):
-    """A call that starts inside a fragment, a small batch without tune_segments, pruning: layout 6 serves them, and the results
-    are the usual ones.  (44.1 kHz — 2205-frame fragments, not a multiple of 16 — and odd strides are k_seg's too.)"""
+    """A small batch without tune_segments, pruning, a call shorter than the fragment it starts in: layout 6 serves them, and the
+    results are the usual ones.  (44.1 kHz — 2205-frame fragments, not a multiple of 16 — odd strides and calls that start inside
+    a fragment are k_seg's too: the rest of the open fragment goes to the wave-per-segment kernel in front of it.)"""
     T = 44100 * 4
     x = np.stack([tri_noise(T, 30 + s, 0.5, period=50000) for s in range(3)])
     got = _run(M, x, [T], 44100.0, tune_segments=4, tune_layout=7)
@@ -102,7 +103,11 @@ def test_seg_not_taken_where_it_does_not_fit(M, oracle):
     x = np.stack([tri_noise(T, 60 + s, 0.5, period=50000) for s in range(3)])
     assert _run(M, x, [T])["seg"][0] == 0                                     # three streams do not fill 65536 lanes
     assert _run(M, x, [T], tune_prune=1, tune_segments=2)["seg"][0] == 0      # pruning is a layout 6 feature
-    assert _run(M, x, [1000, T - 1000], tune_segments=2)["seg"][0] == 0       # 1000 < one fragment, then off the boundary
+    got = _run(M, x, [1000, T - 1000], tune_segments=2)                       # 1000 < one fragment: layout 6; then 1400 frames finish that
+    assert got["seg"] == (1, T - 2400), got["seg"]                            # fragment in front of 79 whole ones
+    for s in range(3):
+        _check_ebu(got, oracle.ebu(x[s], 48000.0, 2400, want_frag=True), s, "head")
+        assert _rel(got["tp"][s], oracle.tp(x[s], 48000.0, 8192)).max() <= TP_RTOL
     got = _run(M, x, [2400 * 3, T - 2400 * 3], tune_segments=2)
     assert got["seg"] == (2, T)
     with M.Engine(3, 48000.0, M.METER_EBU | M.METER_TRUEPEAK, tune_segments=2) as e:
@@ -162,6 +167,23 @@ def test_seg_edge_signals(M, oracle):
     assert _rel(got["tp"][0, 1], ref["tp"][0, 1]) <= TP_RTOL and _rel(got["tp"][1, 0], ref["tp"][1, 0]) <= TP_RTOL
     # (the NaN's own channel: both layouts drop the outputs of the 16-frame columns the NaN reaches)
     assert _rel(got["tp"][1, 1], ref["tp"][1, 1]) <= 1e-2
+
+
+@pytest.mark.parametrize("fs", [48000.0, 44100.0])
+def test_seg_streaming_in_arbitrary_chunks(M, oracle, fs):
+    """A stream fed in chunks that are no multiple of anything: every call but the first starts inside a fragment — the rest of
+    that fragment goes to the wave-per-segment kernel, the whole fragments behind it to k_seg, the remainder to the tail."""
+    fragm = int(fs) // 20
+    calls = [50000, 65536, 33333, 50000, 7 * fragm, 41234]
+    T = sum(calls)
+    x = np.stack([tri_noise(T, 400 + s, 0.7, period=61000) for s in range(4)])
+    got = _run(M, x, calls, fs, tune_segments=2, tune_layout=7)
+    assert got["seg"][0] == len(calls), got["seg"]
+    one = _run(M, x, [T], fs, tune_segments=2, tune_layout=7)
+    for s in range(4):
+        _check_ebu(got, oracle.ebu(x[s], fs, fragm, want_frag=True), s, ("chunks", fs))
+        assert _rel(got["tp"][s], oracle.tp(x[s], fs, 8192)).max() <= TP_RTOL
+    assert _rel(got["tp"], one["tp"]).max() <= 1e-6 and np.allclose(got["frag"], one["frag"], rtol=2e-6)
 
 
 def test_seg_unaligned_tiles_scrub_at_the_exact_frame(M):
