@@ -73,9 +73,10 @@ typedef struct {
 	                          *     accumulation — within 3e-7 relative of a float64 interpolator, like the f32 chain itself;
 	                          *     held to the same 2e-6 relative parity bound as layout 3 (tests/test_gpu_layout6.py),
 	                          * 7 = (auto wherever TRUEPEAK is asked for) layout 6, and for every call that fits it — a batch
-	                          *     big enough to fill the chip's lanes, starting on a 50 ms fragment boundary, 16-frame
-	                          *     fragments, 16-byte aligned streams — the same arithmetic with LANE = TIME SEGMENT
-	                          *     (mtr_seg.hip): whole fragments through that kernel, the rest of the call through layout 6.
+	                          *     big enough to fill the chip's lanes, with at least one whole 50 ms fragment in it; any
+	                          *     sample rate, stride and position in the stream — the same arithmetic with LANE = TIME
+	                          *     SEGMENT (mtr_seg.hip): whole fragments through that kernel, the rest of a fragment the call
+	                          *     started in and what is left behind the last whole one through layout 6.
 	                          * Layouts 1, 2 and 5 of earlier versions no longer exist: MTR_ERR_ARG. */
 	uint32_t tune_fir;       /* layout 3 only: 0 = mirror-symmetric form (120 ops / frame), 1 = dense 3 x 48 taps */
 	uint32_t tune_prune;     /* 1 = exact true-peak pruning (branch and bound on L1 * max|x| per tile): identical result,
