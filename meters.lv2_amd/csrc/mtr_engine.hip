@@ -811,7 +811,6 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 			// the batch path: whole fragments through k_seg; the rest of an open fragment in front of them and what is left of
 			// the call behind them (less than a fragment each) through k_kwtp16, each as ONE segment that picks the K-filter
 			// state up where its predecessor in the stream left it
-			const uint32_t* const all_seg = fa.seg_tile;
 			if (pl.head_tiles) {
 				fa.seg_tile = e->head_seg; fa.n_segs = 1;
 				lrc = mtr_launch_kwtp16 (e->run, ebu, fa, S, st);
@@ -831,7 +830,6 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 				fa.seg_tile = e->tail_seg; fa.n_segs = 1;
 				lrc = mtr_launch_kwtp16 (e->run, ebu, fa, S, st);
 			}
-			(void) all_seg;
 			e->seg_calls += 1; e->seg_frames += (uint64_t) sp.tiles * e->fragm;
 		} else {
 			lrc = e->layout == 6 ? mtr_launch_kwtp16 (e->run, ebu, fa, S * pl.n_segs, st)
