@@ -26,8 +26,9 @@
 //     power-of-two scale (from the window's maximum) — nothing is staged as f16.
 //   * eight waves, two per SIMD (waves w and w + 4 share one; every role is a dependent sequence and a second wave
 //     covers its latencies), balanced by instruction count: wave 0 walks the 64 chains (chunk t - 2); waves 1, 2, 3
-//     and 7 run the products of chunk t, one block of 18 MFMAs each, and leave w1 v, w2 v of the four values of every
-//     frame in LDS; waves 4, 5, 6 form the per-frame maps of chunk t - 1 (lane = column; 4, 6 and 6 frames) and wave 4
+//     and 7 run the products of chunk t, one block of 18 MFMAs each, and leave the four values of every frame in LDS
+//     (16 bytes per frame and column: carrying w1 v, w2 v instead costs more LDS traffic than the eight multiplies it
+//     saves the map lanes — 35.5 vs 34.3 ms); waves 4, 5, 6 form the per-frame maps of chunk t - 1 (lane = column; 4, 6 and 6 frames) and wave 4
 //     fetches chunk t + 1.  Values and maps are double buffered in LDS, one barrier per chunk.
 #include <hip/hip_runtime.h>
 
@@ -68,7 +69,7 @@ constexpr int NCOL = 64;                       // (stream, channel) columns per 
 constexpr int RING = 5 * F;                    // samples per column: the 64-sample window of a chunk + the chunk being fetched
 constexpr int RSTRIDE = RING + 4;              // floats per column (16-byte rows; 84 = 20 mod 64: sixteen columns hit sixteen bank groups)
 constexpr int RING_B = NCOL * RSTRIDE * 4;
-constexpr int VBUF_B = F * 2 * NCOL * 16;      // a chunk of values: [frame][half][column] x (w1 v, w2 v) of two values; v = |x[n - 24]|, |y1|, |y2|, |y3|
+constexpr int VBUF_B = F * NCOL * 16;          // a chunk of values: [frame][column] x (|x[n - 24]|, |y1|, |y2|, |y3|)
 constexpr int CBUF_B = F * 2 * NCOL * 16;      // a chunk of maps: [frame][half][column] x (c_k of filter 1, of filter 2) for k = 1, 2 | 3, 4
 constexpr int LDS_BYTES = RING_B + 2 * VBUF_B + 2 * CBUF_B;
 constexpr int NTHREADS = 64 * NW;
@@ -226,17 +227,15 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		for (int n = 0; n < NB; ++n) m16::block (A, B[n], y[n]);
 #pragma unroll
 		for (int n = 0; n < NB; ++n) {
-			unsigned char* const dst = vbuf + par * VBUF_B + ((4 * kg) * 2 * NCOL + 16 * (b0 + n) + cc) * 16;
+			unsigned char* const dst = vbuf + par * VBUF_B + ((4 * kg) * NCOL + 16 * (b0 + n) + cc) * 16;
 			const float xr[4] = { x0[n].x, x0[n].y, x0[n].z, x0[n].w };
-			const float u1 = un[n] * a.w1, u2 = un[n] * a.w2;                // (un is a power of two: exact)
 			float pm = 0.f, px = 0.f;
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const float keep = r < nfl ? 1.f : 0.f;
 				px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
 				pm = __builtin_fmaxf (pm, max3f (fabsf (y[n][0][r]), fabsf (y[n][1][r]), fabsf (y[n][2][r])) * keep);      // truepeakdsp.cc:65
-				*reinterpret_cast<float4*> (dst + (r * 2 + 0) * NCOL * 16) = float4{fabsf (xr[r]) * a.w1, fabsf (xr[r]) * a.w2, fabsf (y[n][0][r]) * u1, fabsf (y[n][0][r]) * u2};
-				*reinterpret_cast<float4*> (dst + (r * 2 + 1) * NCOL * 16) = float4{fabsf (y[n][1][r]) * u1, fabsf (y[n][1][r]) * u2, fabsf (y[n][2][r]) * u1, fabsf (y[n][2][r]) * u2};
+				*reinterpret_cast<float4*> (dst + r * NCOL * 16) = float4{fabsf (xr[r]), fabsf (y[n][0][r]) * un[n], fabsf (y[n][1][r]) * un[n], fabsf (y[n][2][r]) * un[n]};
 			}
 			pk[n] = max3f (pk[n], px, pm * un[n]);
 		}
@@ -247,16 +246,14 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		if constexpr (F1 > F0) {
 		const unsigned char* const src = vbuf + par * VBUF_B + lane * 16;
 		unsigned char* const dst = cbuf + par * CBUF_B + lane * 16;
-		float4 va[F1 - F0], vb[F1 - F0];                                 // every value first: the stores below would otherwise order the reads
+		const v2f W = v2f{a.w1, a.w2};
+		float4 va[F1 - F0];
 #pragma unroll
-		for (int f = F0; f < F1; ++f) {
-			va[f - F0] = *reinterpret_cast<const float4*> (src + (f * 2 + 0) * NCOL * 16);
-			vb[f - F0] = *reinterpret_cast<const float4*> (src + (f * 2 + 1) * NCOL * 16);
-		}
+		for (int f = F0; f < F1; ++f) va[f - F0] = *reinterpret_cast<const float4*> (src + f * NCOL * 16);
 		v2f g1[F1 - F0], g2[F1 - F0], g3[F1 - F0], g4[F1 - F0];
 #pragma unroll
 		for (int f = F0; f < F1; ++f) {
-			const v2f b1 = v2f{va[f - F0].x, va[f - F0].y}, b2 = v2f{va[f - F0].z, va[f - F0].w}, b3 = v2f{vb[f - F0].x, vb[f - F0].y}, b4 = v2f{vb[f - F0].z, vb[f - F0].w};
+			const v2f b1 = W * va[f - F0].x, b2 = W * va[f - F0].y, b3 = W * va[f - F0].z, b4 = W * va[f - F0].w;
 			const v2f d1 = max2 (b1, b2), d2 = fma2 (AA, b1, b2);
 			const v2f e1 = max2 (d1, b3), e2 = max2 (d2, fma2 (AA, d1, b3)), e3 = fma2 (AA, d2, b3);
 			g1[f - F0] = max2 (e1, b4); g2[f - F0] = max2 (e2, fma2 (AA, e1, b4)); g3[f - F0] = max2 (e3, fma2 (AA, e2, b4)); g4[f - F0] = fma2 (AA, e3, b4);
