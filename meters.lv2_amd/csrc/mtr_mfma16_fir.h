@@ -1,4 +1,4 @@
-// mtr_mfma16_fir.h — the 4x interpolator on the matrix pipe at f32 grade (gfx950), layout 6.
+// mtr_mfma16_fir.h — the 4x interpolator on the matrix pipe at f32 grade (gfx950): layouts 6 and 7 (k_kwtp16, k_seg) and k_tpb.
 //
 // y_p[n] = sum_i g_p[i] x[n - 47 + i]  (p = 1..3; phase 0 is x[n - 24] itself and stays on the VALU) is a
 // block-Toeplitz product.  Samples AND taps are carried as two f16 halves each,

@@ -419,7 +419,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	};
 
 	// one step: the scalar / packed work of step j on buffer U (ring slot U), and — PROD — the products of step j - 1,
-	// interleaved by sched_group_barrier: VPM VALU instructions behind every MFMA
+	// interleaved by hand (the source order is the schedule: see the chunks below)
 #ifdef MTR_SEG_PROF
 	unsigned long long sprof_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
