@@ -239,6 +239,25 @@ int  mtr_engine_layout (const mtr_engine* e);
 /* Layout 7: process calls whose whole fragments went through the lane = time segment kernel, and the frames per stream
  * it covered, since the engine was created (the calls that did not fit it ran layout 6). */
 int  mtr_engine_seg_stats (mtr_engine* e, uint64_t* calls, uint64_t* frames_per_stream);
+/* How an engine of this configuration would tile and route a call of `n_frames` that starts with `frames_left_in_fragment`
+ * frames of a 50 ms fragment still open (0 or sample_rate / 20: on a boundary): pure host arithmetic, no device needed —
+ * the planning logic of mtr_engine_process_* (no reference counterpart: the reference walks its samples one by one,
+ * ebumeter/ebu_r128_proc.cc:217-244).  n_slots = resident lane = segment waves to plan for (0: 1024, an MI355X). */
+typedef struct mtr_plan_info {
+	uint32_t layout;            /* as mtr_engine_layout () */
+	uint32_t uses_seg;          /* 1: the call's whole fragments go through the lane = time segment kernel */
+	uint32_t head_frames;       /* frames in front of them (the rest of the open fragment), through the wave-per-segment kernel */
+	uint32_t body_fragments;    /* whole fragments through the lane = segment kernel */
+	uint32_t segments;          /* ... cut into this many time segments per stream */
+	uint32_t fragments_per_lane;/* ... of which every lane walks this many (a short segment starts one early) */
+	uint32_t warm_steps;        /* K-filter warm-up in front of a segment that does not start the body: steps of 16 frames */
+	uint32_t n_tiles;           /* tiles of the whole call (head + body + tail) */
+	uint32_t head_tiles;        /* ... of which in front of the body */
+	uint32_t n_fragments_ended; /* fragments that end inside the call */
+	uint32_t kw_segments;       /* time segments per stream of a call that does not use the lane = segment kernel */
+	uint32_t frames_left_after; /* of the fragment open when the call returns */
+} mtr_plan_info;
+int  mtr_plan_query (const mtr_config* cfg, uint32_t frames_left_in_fragment, uint64_t n_frames, uint32_t n_slots, mtr_plan_info* out);
 /* K-weighting coefficients a0 a1 a2 b1 b2 c3 c4 at `sample_rate` (Ebu_r128_proc::detect_init,
  * ebumeter/ebu_r128_proc.cc:263-293) */
 int  mtr_kweight_coef (float sample_rate, float* out7);

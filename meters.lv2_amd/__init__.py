@@ -9,5 +9,5 @@ when the library has not been built.
 from .engine import (  # noqa: F401
     Engine, EngineError, StreamResult, lib, lib_path, Comm, comm_unique_id,
     METER_EBU, METER_TRUEPEAK, METER_SPECTR30, METER_TPBALLIST, METER_BITSTATS, METER_SIGDIST, METER_DR14, METER_KMETER,
-    fir_table, kweight_coef, band_coef, hist_loudness, synth_fill_device, exported_symbols,
+    fir_table, kweight_coef, band_coef, hist_loudness, synth_fill_device, exported_symbols, plan_query,
 )

@@ -274,6 +274,28 @@ void mtr_hist_loudness (const int32_t* hm, const int32_t* hs, float* integ, floa
 	if (rthr) *rthr = d[4];
 }
 
+// Which kernels serve a configuration (pure: mtr_engine_create and mtr_plan_query share it).  Returns what is wrong with it, or NULL.
+static const char* resolve_layout (const mtr_config* cfg, int* layout, int* run, bool* seg_ok)
+{
+	if (cfg->tune_run != 0 && cfg->tune_run != 19 && cfg->tune_run != 38 && cfg->tune_run != 39) return "tune_run must be 0, 19, 38 or 39";
+	if (cfg->tune_layout != 0 && cfg->tune_layout != 3 && cfg->tune_layout != 4 && cfg->tune_layout != 6 && cfg->tune_layout != 7)
+		return "tune_layout must be 0, 3, 4, 6 or 7 (layouts 1, 2 and 5 of earlier versions are gone)";
+	if (cfg->tune_fir > 1) return "tune_fir must be 0 or 1";
+	const bool kw_only = (cfg->meters & MTR_METER_EBU) && !(cfg->meters & MTR_METER_TRUEPEAK);
+	const bool has_tp = cfg->meters & MTR_METER_TRUEPEAK;
+	int lay = cfg->tune_layout ? (int) cfg->tune_layout : kw_only ? 4 : (has_tp && (cfg->tune_run == 0 || cfg->tune_run == 38)) ? 7 : 3;
+	*seg_ok = lay == 7 && cfg->tune_prune == 0;
+	if (lay == 7) lay = 6;
+	*layout = lay;
+	*run = cfg->tune_run ? (int) cfg->tune_run : (lay == 6 ? 38 : 39);
+	if ((lay == 6) != (*run == 38)) return "layouts 6 and 7 run 38-frame lane runs, and only they do";
+	if (lay == 6 && !has_tp) return "layouts 6 and 7 are true-peak kernels: need TRUEPEAK";
+	if (lay == 4 && !kw_only) return "layout 4 is the EBU-only kernel";
+	if (lay == 3 && *run != 39) return "layout 3 needs tune_run 39";
+	if (lay == 4 && *run != 39 && *run != 19) return "layout 4 needs tune_run 19 or 39";
+	return nullptr;
+}
+
 int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 {
 	if (!cfg || !out || cfg->struct_size != sizeof (mtr_config)) return fail (MTR_ERR_ARG, "mtr_engine_create: bad config");
@@ -287,10 +309,10 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 		return fail (MTR_ERR_UNSUPPORTED, "EBU / TRUEPEAK need stereo frames (the reference's EBUr128 plugin is stereo only)");
 	if ((cfg->meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) && cfg->n_channels != 1)
 		return fail (MTR_ERR_UNSUPPORTED, "BITSTATS / SIGDIST take mono streams (the reference's bitmeter / SigDistHist are mono plugins)");
-	if (cfg->tune_run != 0 && cfg->tune_run != 19 && cfg->tune_run != 38 && cfg->tune_run != 39) return fail (MTR_ERR_ARG, "tune_run must be 0, 19, 38 or 39");
-	if (cfg->tune_layout != 0 && cfg->tune_layout != 3 && cfg->tune_layout != 4 && cfg->tune_layout != 6 && cfg->tune_layout != 7)
-		return fail (MTR_ERR_ARG, "tune_layout must be 0, 3, 4, 6 or 7 (layouts 1, 2 and 5 of earlier versions are gone)");
-	if (cfg->tune_fir > 1) return fail (MTR_ERR_ARG, "tune_fir must be 0 or 1");
+	{
+		int l_, r_; bool k_;
+		if (const char* why = resolve_layout (cfg, &l_, &r_, &k_)) return fail (MTR_ERR_ARG, why);
+	}
 
 	int ndev = 0;
 	if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0)
@@ -307,18 +329,10 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	// layout 7 (the default with a true peak) = layout 6 plus k_seg (mtr_seg.hip, lane = time segment) for every call that
 	//            fits it: a big batch that starts on a fragment boundary (seg_plan below);
 	// layout 3 = the exact-f32 VALU interpolator (mtr_fused2.hip), kept as the bit-for-bit cross-check of the matrix-pipe paths.
-	const bool kw_only = (cfg->meters & MTR_METER_EBU) && !(cfg->meters & MTR_METER_TRUEPEAK);
-	const bool has_tp = cfg->meters & MTR_METER_TRUEPEAK;
-	int lay = cfg->tune_layout ? (int) cfg->tune_layout : kw_only ? 4 : (has_tp && (cfg->tune_run == 0 || cfg->tune_run == 38)) ? 7 : 3;
-	e->seg_ok = lay == 7 && cfg->tune_prune == 0;
-	if (lay == 7) lay = 6;
-	e->layout = lay;
-	e->run = cfg->tune_run ? (int) cfg->tune_run : (e->layout == 6 ? 38 : 39);
-	if ((e->layout == 6) != (e->run == 38)) { delete e; return fail (MTR_ERR_ARG, "layouts 6 and 7 run 38-frame lane runs, and only they do"); }
-	if (e->layout == 6 && !has_tp) { delete e; return fail (MTR_ERR_ARG, "layouts 6 and 7 are true-peak kernels: need TRUEPEAK"); }
-	if (e->layout == 4 && !kw_only) { delete e; return fail (MTR_ERR_ARG, "layout 4 is the EBU-only kernel"); }
-	if (e->layout == 3 && e->run != 39) { delete e; return fail (MTR_ERR_ARG, "layout 3 needs tune_run 39"); }
-	if (e->layout == 4 && e->run != 39 && e->run != 19) { delete e; return fail (MTR_ERR_ARG, "layout 4 needs tune_run 19 or 39"); }
+	{
+		const char* why = resolve_layout (cfg, &e->layout, &e->run, &e->seg_ok);
+		if (why) { delete e; return fail (MTR_ERR_ARG, why); }
+	}
 	{
 		hipDeviceProp_t pr;
 		if (hipGetDeviceProperties (&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->seg_slots = 4u * (uint32_t) pr.multiProcessorCount;
@@ -600,9 +614,24 @@ struct SegPlan {
 // resident waves x steps per wave, a warm-up step (K-filter only) at 0.3 of a full one — and the call takes this path
 // when that beats the model of k_kwtp16 (1.2 x the time per frame when both fill the machine, measured: 11.7 vs 9.75 ms,
 // profiles/r03*; k_kwtp16's waves are a stream-tile each, so it fills the machine with any batch).
-static SegPlan seg_plan (const mtr_engine* e, const float* d_audio, uint64_t N, uint64_t stride)
+// (everything the planning needs from an engine: mtr_plan_query builds one from a configuration alone, without a device)
+struct PlanCtx {
+	mtr_config cfg;
+	bool       seg_ok;
+	int        layout, run;
+	uint32_t   fragm, frcnt, seg_slots;
+};
+static PlanCtx plan_ctx (const mtr_engine* e)
+{
+	PlanCtx c;
+	c.cfg = e->cfg; c.seg_ok = e->seg_ok; c.layout = e->layout; c.run = e->run; c.fragm = e->fragm; c.frcnt = e->frcnt; c.seg_slots = e->seg_slots;
+	return c;
+}
+
+static SegPlan seg_plan (const PlanCtx* e, const float* d_audio, uint64_t N, uint64_t stride)
 {
 	SegPlan sp;
+	(void) stride;
 	const bool ebu = e->cfg.meters & MTR_METER_EBU;
 	if (!e->seg_ok || e->layout != 6 || e->cfg.n_channels != 2) return sp;
 	if (e->fragm < 4 * MTR_SEG_STEP) return sp;
@@ -651,17 +680,19 @@ static void plan_abort (mtr_engine* e, hipStream_t st)
 	e->plan.valid = false;
 }
 
-// Tiling plan for a call of n_frames starting with `frcnt` frames left in the open fragment.  body_tiles > 0: behind the
+// Tiling of a call of N frames that starts with `frcnt` frames left in the open fragment (pure).  body_tiles > 0: behind the
 // `head` frames that finish the open fragment (0 if the call starts on a boundary) body_tiles tiles are whole fragments
 // (k_seg's part), whatever their length.
-static int build_plan (mtr_engine* e, uint64_t N, uint32_t head, uint32_t body_tiles, hipStream_t st)
+struct Tiling {
+	std::vector<uint32_t> ts, ft, sg;       // tile starts (+ N), first tile of every fragment that ends in the call, segment starts
+	uint32_t n_tiles = 0, n_frag = 0, tail = 0, head_tiles = 0, n_segs = 0, frcnt_out = 0, maxlen = 0;
+};
+static const char* plan_tiling (const PlanCtx* e, uint64_t N, uint32_t head, uint32_t body_tiles, Tiling& t)
 {
-	Plan& pl = e->plan;
-	if (pl.valid && pl.n_frames == N && pl.frcnt_in == e->frcnt && pl.body_tiles == body_tiles) return MTR_OK;
-	pl.valid = false;
 	const uint32_t LT = 64u * (uint32_t) e->run;
-
-	std::vector<uint32_t> ts, ft;
+	std::vector<uint32_t>& ts = t.ts;
+	std::vector<uint32_t>& ft = t.ft;
+	ts.clear (); ft.clear ();
 	ts.reserve ((size_t) (N / LT + N / e->fragm + 4));
 	uint64_t pos = 0;
 	uint32_t left = e->frcnt;
@@ -698,10 +729,30 @@ static int build_plan (mtr_engine* e, uint64_t N, uint32_t head, uint32_t body_t
 	n_segs = (uint32_t) std::min<uint64_t> (n_segs, max_segs);
 	if (body_tiles) n_segs = 1;                                 // k_kwtp16 only starts / finishes such a call: one segment each (head_seg, tail_seg)
 	n_segs = std::max<uint32_t> (1, std::min<uint32_t> (n_segs, n_tiles));
-	std::vector<uint32_t> sg (n_segs + 1);
-	for (uint32_t q = 0; q <= n_segs; ++q) sg[q] = (uint32_t) ((uint64_t) q * n_tiles / n_segs);
+	t.sg.assign (n_segs + 1, 0);
+	for (uint32_t q = 0; q <= n_segs; ++q) t.sg[q] = (uint32_t) ((uint64_t) q * n_tiles / n_segs);
 	for (uint32_t q = 1; q < n_segs; ++q)
-		if ((uint64_t) ts[sg[q]] < (uint64_t) warm_tiles * LT) return fail (MTR_ERR_ARG, "internal: segment shorter than its warm-up");
+		if ((uint64_t) ts[t.sg[q]] < (uint64_t) warm_tiles * LT) return "internal: segment shorter than its warm-up";
+	t.n_tiles = n_tiles; t.n_frag = n_frag; t.tail = tail; t.head_tiles = head_tiles; t.n_segs = n_segs; t.frcnt_out = left;
+	t.maxlen = n_segs > 1 ? LT : 0;                             // warm-up tiles are full tiles
+	for (uint32_t j = 0; j < n_tiles; ++j)
+		if (j < head_tiles || j >= head_tiles + body_tiles) t.maxlen = std::max (t.maxlen, ts[j + 1] - ts[j]);
+	return nullptr;
+}
+
+// The plan of a call on the device: the tiling above in the next slot of the plan ring.
+static int build_plan (mtr_engine* e, uint64_t N, uint32_t head, uint32_t body_tiles, hipStream_t st)
+{
+	Plan& pl = e->plan;
+	if (pl.valid && pl.n_frames == N && pl.frcnt_in == e->frcnt && pl.body_tiles == body_tiles) return MTR_OK;
+	pl.valid = false;
+	const PlanCtx ctx = plan_ctx (e);
+	Tiling til;
+	if (const char* why = plan_tiling (&ctx, N, head, body_tiles, til)) return fail (MTR_ERR_ARG, why);
+	const std::vector<uint32_t>& ts = til.ts;
+	const std::vector<uint32_t>& ft = til.ft;
+	const std::vector<uint32_t>& sg = til.sg;
+	const uint32_t n_tiles = til.n_tiles, n_frag = til.n_frag, tail = til.tail, head_tiles = til.head_tiles, n_segs = til.n_segs, left = til.frcnt_out;
 
 	// (with head-room: an LV2 host's blocks see a fragment end in some calls and none in others, and a buffer that grows
 	// by one word then is a hipMalloc — 0.3 ms — in the audio thread)
@@ -731,9 +782,7 @@ static int build_plan (mtr_engine* e, uint64_t N, uint32_t head, uint32_t body_t
 
 	pl.n_frames = N; pl.frcnt_in = e->frcnt; pl.frcnt_out = left;
 	pl.n_tiles = n_tiles; pl.n_frag = n_frag; pl.n_segs = n_segs; pl.tail_tile = tail; pl.body_tiles = body_tiles; pl.head_tiles = head_tiles;
-	uint32_t maxlen = n_segs > 1 ? LT : 0;                      // warm-up tiles are full tiles
-	for (uint32_t j = 0; j < n_tiles; ++j)
-		if (j < head_tiles || j >= head_tiles + body_tiles) maxlen = std::max (maxlen, ts[j + 1] - ts[j]);
+	const uint32_t maxlen = til.maxlen;
 	// + look-ahead frames of the FIR register tile + 4 slots for the carried K-filter state (layout 3)
 	pl.buf_slots = (maxlen + 48 + 13 + 4 + 127) / 128 * 128;
 	pl.kw_slots = (maxlen + 1 + 127) / 128 * 128;               // k_kw: the tile + one frame of alignment slack
@@ -785,7 +834,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (tm) { hipEvent_t v = next_event (e, ev0); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 	if (ebu || tp) {
-		const SegPlan sp = seg_plan (e, d_audio, n_frames, stride);
+		const PlanCtx pctx = plan_ctx (e);
+		const SegPlan sp = seg_plan (&pctx, d_audio, n_frames, stride);
 		int rc = build_plan (e, n_frames, sp.use ? sp.head : 0, sp.use ? sp.tiles : 0, st);
 		if (rc) return rc;
 		const Plan& pl = e->plan;
@@ -1204,6 +1254,33 @@ int mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max
 }
 
 int mtr_engine_layout (const mtr_engine* e) { return e ? (e->seg_ok ? 7 : e->layout) : MTR_ERR_ARG; }
+
+int mtr_plan_query (const mtr_config* cfg, uint32_t frames_left_in_fragment, uint64_t n_frames, uint32_t n_slots, mtr_plan_info* out)
+{
+	if (!cfg || !out) return fail (MTR_ERR_ARG, "null argument");
+	if (cfg->n_streams == 0 || !(cfg->sample_rate >= 1000.0f) || n_frames == 0 || n_frames > 0xffffffffull) return fail (MTR_ERR_ARG, "mtr_plan_query: streams, rate or frames out of range");
+	PlanCtx c;
+	c.cfg = *cfg;
+	if (const char* why = resolve_layout (cfg, &c.layout, &c.run, &c.seg_ok)) return fail (MTR_ERR_ARG, why);
+	c.fragm = (uint32_t) ((int) cfg->sample_rate / 20);
+	c.frcnt = frames_left_in_fragment ? frames_left_in_fragment : c.fragm;
+	if (c.frcnt > c.fragm) return fail (MTR_ERR_ARG, "mtr_plan_query: more frames left than a fragment has");
+	c.seg_slots = n_slots ? n_slots : 1024;
+	memset (out, 0, sizeof (*out));
+	const bool fused = cfg->meters & (MTR_METER_EBU | MTR_METER_TRUEPEAK);
+	out->layout = c.seg_ok ? 7u : (uint32_t) c.layout;
+	if (!fused) { out->frames_left_after = c.frcnt; return MTR_OK; }
+	const SegPlan sp = seg_plan (&c, nullptr, n_frames, n_frames);
+	Tiling t;
+	if (const char* why = plan_tiling (&c, n_frames, sp.use ? sp.head : 0, sp.use ? sp.tiles : 0, t)) return fail (MTR_ERR_ARG, why);
+	out->uses_seg = sp.use;
+	out->head_frames = sp.use ? sp.head : 0; out->body_fragments = sp.use ? sp.tiles : 0; out->segments = sp.use ? sp.n_segs : 0;
+	out->fragments_per_lane = sp.use ? sp.n_main : 0; out->warm_steps = sp.use ? sp.warm_steps : 0;
+	out->n_tiles = t.n_tiles; out->head_tiles = t.head_tiles; out->n_fragments_ended = t.n_frag;
+	out->kw_segments = sp.use ? 0 : t.n_segs;
+	out->frames_left_after = t.frcnt_out;
+	return MTR_OK;
+}
 
 int mtr_engine_seg_stats (mtr_engine* e, uint64_t* calls, uint64_t* frames)
 {

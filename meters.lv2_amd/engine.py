@@ -32,6 +32,15 @@ class _Config(C.Structure):
                 ("tune_layout", C.c_uint32), ("tune_fir", C.c_uint32), ("tune_prune", C.c_uint32)]
 
 
+class PlanInfo(C.Structure):
+    """mtr_plan_info: how an engine would tile and route a call (mtr_plan_query: host arithmetic, no device)."""
+    _fields_ = [(n, C.c_uint32) for n in ("layout", "uses_seg", "head_frames", "body_fragments", "segments", "fragments_per_lane",
+                                          "warm_steps", "n_tiles", "head_tiles", "n_fragments_ended", "kw_segments", "frames_left_after")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class Dr14Result(C.Structure):
     """mtr_dr14_result: what dr14_run leaves on the dr14 plugins' ports in dr_operation_mode."""
     _fields_ = [("m_rms", C.c_float * 2), ("m_peak", C.c_float * 2), ("dr", C.c_float * 2),
@@ -105,6 +114,7 @@ def _load():
     L.mtr_engine_refine_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.mtr_engine_layout.argtypes = [vp]
     L.mtr_engine_seg_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.mtr_plan_query.argtypes = [vp, u32, u64, u32, vp]
     L.mtr_comm_unique_id.argtypes = [vp]
     L.mtr_comm_init.argtypes = [C.POINTER(vp), i32, i32, vp, i32]
     L.mtr_comm_destroy.argtypes = [vp]
@@ -161,6 +171,17 @@ def hist_loudness(hist_M, hist_S):
     o = [C.c_float() for _ in range(5)]
     lib.mtr_hist_loudness(hm.ctypes.data, hs.ctypes.data, *[C.byref(x) for x in o])
     return tuple(x.value for x in o)
+
+
+def plan_query(n_streams, n_frames, sample_rate=48000.0, meters=METER_EBU | METER_TRUEPEAK, frames_left_in_fragment=0, n_slots=0,
+               n_channels=2, tune_run=0, tune_segments=0, tune_layout=0, tune_fir=0, tune_prune=0):
+    """How an engine of this configuration would tile and route a call (no GPU needed)."""
+    cfg = _Config(struct_size=C.sizeof(_Config), meters=meters, n_streams=n_streams, n_channels=n_channels, sample_rate=sample_rate,
+                  device=0, max_frames=0, tune_run=tune_run, tune_segments=tune_segments, tune_layout=tune_layout, tune_fir=tune_fir,
+                  tune_prune=tune_prune)
+    info = PlanInfo()
+    _check(lib.mtr_plan_query(C.byref(cfg), frames_left_in_fragment, n_frames, n_slots, C.byref(info)), "mtr_plan_query")
+    return info.as_dict()
 
 
 def synth_fill_device(ptr, n_streams, n_frames, stride, seed, fs=48000.0, kind=1, stream=0):
