@@ -449,3 +449,52 @@ def test_truepeak_ballistics_batch(M, oracle):
                 oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
                 assert abs(got[i][s][c][0] - m.value) < 2e-6 * max(1.0, m.value), (s, c, i)
                 assert abs(got[i][s][c][1] - p.value) < 2e-6 * max(1.0, p.value), (s, c, i)
+
+
+def test_truepeak_ballistics_full_size_properties(M, oracle):
+    """TruePeakdsp::process at the per-GPU shard of the bench (8192 streams x 10 s) through size-independent properties:
+    determinism; exact x2 scaling (a power-of-two gain is exact in fp32, in the f16 split — the column's scale moves with
+    it — in the per-frame maps and on the chain: level and peak double exactly while the state stays under the clamp at 20);
+    position independence; and the oracle (the reference's own object) on streams sampled out of the batch, fed in the
+    8192-frame blocks TruePeakdsp::process allows."""
+    import ctypes as C
+    import torch
+    from _oracle import MoTp
+    S, T, fs = 8192, 480000, 48000.0
+    free, _ = torch.cuda.mem_get_info()
+    if free < (S * T * 8) * 1.05:
+        S = int(free * 0.9 / (T * 8)) // 256 * 256
+    buf = torch.empty((S, T, 2), dtype=torch.float32, device="cuda")
+    M.synth_fill_device(buf.data_ptr(), S, T, T, 4242, fs, 1)
+    torch.cuda.synchronize()
+
+    def run(ptr, n=S):
+        with M.Engine(n, fs, M.METER_TPBALLIST) as e:
+            e.process_device(ptr, T)
+            r = e.results()
+            return np.array([[r[s].tpb_level[0], r[s].tpb_level[1], r[s].tpb_peak[0], r[s].tpb_peak[1]] for s in range(n)], np.float32)
+
+    a = run(buf.data_ptr())
+    assert np.array_equal(a, run(buf.data_ptr()))                       # deterministic
+    assert np.all(a > 0) and np.all(a[:, :2] < 20.0)
+    pick = [0, 1, S // 2 + 3, S - 1]
+    for s in pick:
+        xs = buf[s].cpu().numpy()
+        for c in range(2):
+            ch = np.ascontiguousarray(xs[:, c])
+            t = MoTp()
+            oracle.lib.mo_tp_init(C.byref(t), fs)
+            m, p = C.c_float(), C.c_float()
+            mm = pp = 0.0
+            for o in range(0, T, 8192):                                 # read (m, p) restarts the maxima: the call's are the maxima of the blocks'
+                seg = np.ascontiguousarray(ch[o:o + 8192])
+                oracle.lib.mo_tp_process(C.byref(t), seg, seg.size)
+                oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
+                mm, pp = max(mm, m.value), max(pp, p.value)
+            assert abs(a[s, c] - mm) < 2e-6 * max(1.0, mm), (s, c, a[s, c], mm)
+            assert abs(a[s, 2 + c] - pp) < 2e-6 * max(1.0, pp), (s, c, a[s, 2 + c], pp)
+    small = torch.stack([buf[s] for s in pick])
+    assert np.array_equal(run(small.data_ptr(), len(pick)), a[pick])    # the same audio at another batch index: the same numbers
+    buf.mul_(2.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(run(buf.data_ptr()), 2 * a)                   # level and peak double exactly
