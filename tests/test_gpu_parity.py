@@ -307,13 +307,14 @@ def test_aggregate_for_multi_gpu_reduce(M, oracle):
 
 
 @pytest.mark.timeout(900)
-def test_full_size_properties(M, oracle):
+@pytest.mark.parametrize("fs", [48000.0, 44100.0])
+def test_full_size_properties(M, oracle, fs):
     """BASELINE.json's per-GPU shard (8192 streams x 10 s, 31.5 GB) through size-independent
     properties: determinism, exact x2 scaling (power-of-two gain is exact in fp32: peaks double
     exactly, fragment powers quadruple exactly, LUFS moves by 20 log10 2), position independence,
     and oracle parity on streams sampled out of the full batch."""
     import torch
-    S, T, fs = 8192, 480000, 48000.0
+    S, T = 8192, int(fs) * 10                                # (44.1 kHz: fragments of 2205 frames end inside k_seg's 16-frame steps)
     free, _ = torch.cuda.mem_get_info()
     if free < (S * T * 8) * 1.05:
         S = int(free * 0.9 / (T * 8)) // 256 * 256
@@ -335,7 +336,7 @@ def test_full_size_properties(M, oracle):
         assert np.array_equal(u, v)                         # deterministic
     host = {s: buf[s].cpu().numpy() for s in pick}
     for s in pick:                                           # oracle parity on sampled streams
-        o = oracle.ebu(host[s], fs, 2400)
+        o = oracle.ebu(host[s], fs, int(fs) // 20)
         assert np.allclose(a[0][s, :4], o["out9"][:4], atol=DB_TOL), s
         assert abs(a[0][s, 4] - o["out9"][4]) <= CONTRACT_DB
         assert np.allclose(a[1][s], oracle.tp(host[s], fs, 8192), rtol=2e-6), s
