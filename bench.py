@@ -81,10 +81,11 @@ def cpu_baseline(host_audio, fs, budget_s=12.0):
 
 
 def kernel_sha():
-    """Hash of the sources of the dominant kernel: the committed PMC traffic figure is valid for exactly this code."""
+    """Hash of the sources of the dominant kernel — and of the header that fixes how much of a stream its segments re-read
+    for their warm-up: the committed PMC traffic figure is valid for exactly this code."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("mtr_seg.hip", "mtr_mfma16_fir.h", "Makefile"):
+    for f in ("mtr_seg.hip", "mtr_mfma16_fir.h", "mtr_internal.h", "Makefile"):
         h.update(open(os.path.join(ROOT, "meters.lv2_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
