@@ -47,6 +47,19 @@ typedef struct {
 	LV2_URID (*map) (LV2_URID_Map_Handle handle, const char* uri);
 } LV2_URID_Map;
 
+/* ---- options + buf-size: the host's promise about block lengths (lv2plug.in/ns/ext/options, .../buf-size) ---- */
+#define LV2_OPTIONS__options         "http://lv2plug.in/ns/ext/options#options"
+#define LV2_BUF_SIZE__maxBlockLength "http://lv2plug.in/ns/ext/buf-size#maxBlockLength"
+typedef enum { LV2_OPTIONS_INSTANCE, LV2_OPTIONS_RESOURCE, LV2_OPTIONS_BLANK, LV2_OPTIONS_PORT } LV2_Options_Context;
+typedef struct {
+	LV2_Options_Context context;
+	uint32_t            subject;
+	LV2_URID            key;      /* the array ends with key == 0 */
+	uint32_t            size;
+	LV2_URID            type;
+	const void*         value;
+} LV2_Options_Option;
+
 /* ---- atom (binary layout; all bodies padded to 8 bytes inside containers) ------------------ */
 #define LV2_ATOM_URI        "http://lv2plug.in/ns/ext/atom"
 #define LV2_ATOM__Blank     LV2_ATOM_URI "#Blank"

@@ -87,7 +87,7 @@ LV2_Handle dr14_instantiate (const LV2_Descriptor* d, double rate, const char* p
 	cfg.n_streams = 1;
 	cfg.n_channels = p->channels;
 	cfg.sample_rate = (float) rate;
-	if (lv2_engine_open (&cfg, &p->engine) != MTR_OK) {
+	if (lv2_engine_open (&cfg, features, &p->engine) != MTR_OK) {
 		fprintf (stderr, "meters_amd: %s: %s\n", d->URI, mtr_last_error ());
 		free (p);
 		return NULL;

@@ -163,7 +163,7 @@ LV2_Handle ebur128_instantiate (const LV2_Descriptor* d, double rate, const char
 	cfg.n_streams = 1;
 	cfg.n_channels = 2;
 	cfg.sample_rate = (float) rate;
-	if (lv2_engine_open (&cfg, &p->amd) != MTR_OK) {
+	if (lv2_engine_open (&cfg, features, &p->amd) != MTR_OK) {
 		fprintf (stderr, "meters_amd: EBUr128: %s\n", mtr_last_error ());
 		free (p->ring_s); free (p->ring_m); free (p);
 		return NULL;

@@ -87,7 +87,7 @@ static IntStat* common_instantiate (const LV2_Feature* const* features, double r
 	cfg.n_streams = 1;
 	cfg.n_channels = 1;
 	cfg.sample_rate = (float) rate;
-	if (lv2_engine_open (&cfg, &p->amd) != MTR_OK) {
+	if (lv2_engine_open (&cfg, features, &p->amd) != MTR_OK) {
 		fprintf (stderr, "meters_amd: %s: %s\n", name, mtr_last_error ());
 		free (p);
 		return NULL;

@@ -105,7 +105,7 @@ static LV2_Handle meter_instantiate (const LV2_Descriptor* d, double rate, const
 		cfg.n_streams = 1;
 		cfg.n_channels = self->chn;
 		cfg.sample_rate = (float) rate;
-		if (lv2_engine_open (&cfg, &self->amd) != MTR_OK) {
+		if (lv2_engine_open (&cfg, f, &self->amd) != MTR_OK) {
 			fprintf (stderr, "meters_amd: dBTP: %s\n", mtr_last_error ());
 			free (self);
 			return NULL;
@@ -255,7 +255,7 @@ static LV2_Handle spectrum_instantiate (const LV2_Descriptor* d, double rate, co
 	cfg.n_streams = 1;
 	cfg.n_channels = nch;
 	cfg.sample_rate = (float) rate;
-	if (lv2_engine_open (&cfg, &self->amd) != MTR_OK) {
+	if (lv2_engine_open (&cfg, f, &self->amd) != MTR_OK) {
 		fprintf (stderr, "meters_amd: spectr30: %s\n", mtr_last_error ());
 		free (self);
 		return NULL;

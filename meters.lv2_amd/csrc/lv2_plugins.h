@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "lv2_min.h"
 #include "mtr_engine.h"
@@ -15,15 +16,35 @@
  * leaving the last good values there, so a host or GUI can tell "no measurement" from "unchanged level".  Audio is
  * still passed through. */
 #define MTR_LV2_NO_DATA ((float) NAN)
-/* block size the engine is warmed up for at instantiate (mtr_engine_prepare_host): larger blocks still work, the first
- * one of a larger size pays for its staging buffer */
+/* block size the engine is warmed up for at instantiate (mtr_engine_prepare_host) when the host does not say: larger blocks
+ * still work, the first one of a larger size pays for its staging buffer */
 #define MTR_LV2_MAX_BLOCK 8192u
+/* A host that passes options:options with buf-size:maxBlockLength (an atom:Int; both need urid:map) has promised the largest
+ * block run () will see: that is what gets warmed up.  (The reference does not read the option — its DSP needs no buffers
+ * sized by it, TruePeakdsp::process asserts n <= 8192 instead, jmeters/truepeakdsp.cc:44.) */
+static inline uint32_t lv2_max_block (const LV2_Feature* const* features)
+{
+	const LV2_URID_Map* map = NULL;
+	const LV2_Options_Option* opt = NULL;
+	for (int i = 0; features && features[i]; ++i) {
+		if (!strcmp (features[i]->URI, LV2_URID__map)) map = (const LV2_URID_Map*) features[i]->data;
+		else if (!strcmp (features[i]->URI, LV2_OPTIONS__options)) opt = (const LV2_Options_Option*) features[i]->data;
+	}
+	if (!map || !opt) return MTR_LV2_MAX_BLOCK;
+	const LV2_URID key = map->map (map->handle, LV2_BUF_SIZE__maxBlockLength), t_int = map->map (map->handle, LV2_ATOM__Int);
+	for (; opt->key; ++opt)
+		if (opt->context == LV2_OPTIONS_INSTANCE && opt->key == key && opt->type == t_int && opt->size == sizeof (int32_t) && opt->value) {
+			const int32_t n = *(const int32_t*) opt->value;
+			if (n >= 1 && n <= (1 << 22)) return (uint32_t) n;
+		}
+	return MTR_LV2_MAX_BLOCK;
+}
 /* an engine for one plugin instance, warmed up: what run () does first must not be the allocation and module loading */
-static inline int lv2_engine_open (const mtr_config* cfg, mtr_engine** out)
+static inline int lv2_engine_open (const mtr_config* cfg, const LV2_Feature* const* features, mtr_engine** out)
 {
 	int rc = mtr_engine_create (cfg, out);
 	if (rc != MTR_OK) return rc;
-	rc = mtr_engine_prepare_host (*out, MTR_LV2_MAX_BLOCK);
+	rc = mtr_engine_prepare_host (*out, lv2_max_block (features));
 	if (rc != MTR_OK) { mtr_engine_destroy (*out); *out = NULL; }
 	return rc;
 }

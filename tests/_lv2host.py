@@ -70,13 +70,28 @@ class Host:
         raise KeyError(name)
 
 
+class OptionsOption(C.Structure):
+    """LV2_Options_Option (lv2plug.in/ns/ext/options)."""
+    _fields_ = [("context", C.c_int), ("subject", C.c_uint32), ("key", C.c_uint32), ("size", C.c_uint32), ("type", C.c_uint32),
+                ("value", C.c_void_p)]
+
+
 class Instance:
-    def __init__(self, host, name, rate=48000.0, with_urid_map=True):
+    def __init__(self, host, name, rate=48000.0, with_urid_map=True, max_block_length=None):
+        """max_block_length: passed as options:options { buf-size:maxBlockLength (atom:Int) } like a host that states it."""
         self.host, self.desc = host, host.find(name)
         feats = []
         if with_urid_map:
             self._f = Feature(b"http://lv2plug.in/ns/ext/urid#map", C.cast(C.pointer(host.urid_map), C.c_void_p))
             feats.append(C.pointer(self._f))
+        if max_block_length is not None:
+            self._mbl = C.c_int32(max_block_length)
+            self._opts = (OptionsOption * 2)(
+                OptionsOption(0, 0, host.urid("http://lv2plug.in/ns/ext/buf-size#maxBlockLength"), 4,
+                              host.urid("http://lv2plug.in/ns/ext/atom#Int"), C.cast(C.pointer(self._mbl), C.c_void_p)),
+                OptionsOption(0, 0, 0, 0, 0, None))
+            self._fo = Feature(b"http://lv2plug.in/ns/ext/options#options", C.cast(self._opts, C.c_void_p))
+            feats.append(C.pointer(self._fo))
         arr = (C.POINTER(Feature) * (len(feats) + 1))(*feats, None)
         self._arr = arr
         self.handle = self.desc.instantiate(C.pointer(self.desc), rate, b"/tmp/", arr)

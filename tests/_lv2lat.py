@@ -12,12 +12,12 @@ def _f(v=0.0):
     return np.array([v], np.float32)
 
 
-def _wire(host, name, n, keep):
+def _wire(host, name, n, keep, max_block_length=None):
     """Instantiate `name` with every port connected for blocks of n frames; returns (inst, per_block_hook)."""
     rng = np.random.default_rng(7)
     bl = (rng.uniform(-0.5, 0.5, n)).astype(np.float32)
     br = (rng.uniform(-0.5, 0.5, n)).astype(np.float32)
-    inst = Instance(host, name, rate=48000.0)
+    inst = Instance(host, name, rate=48000.0, max_block_length=max_block_length)
     assert inst.ok(), name
     hook = None
     if name == "EBUr128":
@@ -58,10 +58,10 @@ def _wire(host, name, n, keep):
     return inst, hook
 
 
-def run_latency(host, name, n, blocks=300, warm=30, ui=False):
+def run_latency(host, name, n, blocks=300, warm=30, ui=False, max_block_length=None):
     """-> dict(median_us, p99_us, max_us, budget_us) for blocks of n frames at 48 kHz."""
     keep = {"ui": ui}
-    inst, hook = _wire(host, name, n, keep)
+    inst, hook = _wire(host, name, n, keep, max_block_length)
     t = np.zeros(blocks)
     for i in range(warm + blocks):
         if hook:
