@@ -14,6 +14,8 @@ BANDS = [25, 31, 40, 50, 63, 80, 100, 125, 160, 200, 250, 315, 400, 500, 630, 80
          2500, 3150, 4000, 5000, 6300, 8000, 10000, 12500, 16000, 20000]
 
 PREFIX = """@prefix atom: <http://lv2plug.in/ns/ext/atom#> .
+@prefix bufsz: <http://lv2plug.in/ns/ext/buf-size#> .
+@prefix opts: <http://lv2plug.in/ns/ext/options#> .
 @prefix doap: <http://usefulinc.com/ns/doap#> .
 @prefix lv2:  <http://lv2plug.in/ns/lv2core#> .
 @prefix mtr:  <%s> .
@@ -51,7 +53,9 @@ def plugin(uri, name, comment, ports, extra=""):
     stays on the host CPU do: a run() that copies to the GPU, launches kernels and waits for them takes driver locks,
     however short it is (26 - 132 us per 1024-frame block)."""
     body = " ] , [\n".join(ports)
-    rt = "" if "GPU" in comment else "\tlv2:optionalFeature lv2:hardRTCapable ;\n"
+    # the GPU plugins warm their engine up for the host's largest block when it says what that is (csrc/lv2_plugins.h: lv2_max_block)
+    rt = ("\tlv2:optionalFeature opts:options ;\n\topts:supportedOption bufsz:maxBlockLength ;\n" if "GPU" in comment
+          else "\tlv2:optionalFeature lv2:hardRTCapable ;\n")
     return ("mtr:%s\n\ta lv2:Plugin , lv2:AnalyserPlugin , doap:Project ;\n\tdoap:license <http://usefulinc.com/doap/licenses/gpl> ;\n"
             "\tdoap:name \"%s\" ;\n\tlv2:project <http://gareus.org/oss/lv2/meters> ;\n%s%s"
             "\tlv2:port [\n%s\t] ;\n\trdfs:comment \"%s\"\n\t.\n\n" % (uri, name, rt, extra, body, comment))
