@@ -343,7 +343,7 @@ def main():
                 out["roofline"]["binding_roofline"] = {
                     "bound": "SIMD issue cycles under the power cap: f16 MFMA (3 partial products) with two VALU riders each + the packed recurrence block + LDS",
                     "mfma_pipe_cycles_per_step": 144 * 16, "issue_model_cycles_per_step": model_step,
-                    "profiled_cycles_per_step": (4040.4 if ebu_on else 3120.3) if seg else None,
+                    "profiled_cycles_per_step": (4049.1 if ebu_on else 3104.7) if seg else None,
                     "mfma_pipe_cycles_per_simd": mfma_cycles, "issue_floor_cycles_per_simd": floor_cycles,
                     "kernel_ms_at_floor_and_2p4_ghz": floor_cycles / 2.4e6, "kernel_ms_at_floor_and_profiled_clock_1p58_ghz": floor_cycles / 1.58e6,
                     "frac_of_floor_at_profiled_clock": (floor_cycles / 1.58e6) / k_ms,

@@ -13,7 +13,7 @@
 // tile).  Here a lane owns a whole TIME SEGMENT of a stream (the 64 lanes of a wave = 64 (stream, segment) units) and
 // walks it 16 frames per step:
 //   * the K-filter is the plain recurrence, 11 packed instructions per frame, state in registers; a segment that does
-//     not start the call is warmed up over the 0.1 s in front of it (slowest pole 0.99502 per sample: 4e-11;
+//     not start the call is warmed up over the 0.075 s in front of it (slowest pole 0.99502 per sample: 1.6e-8;
 //     k_kwtp16 warms its own time segments the same way), segment 0 starts from the carried state;
 //   * the 16 new frames of a lane are ONE column of the block-Toeplitz product: rows = the 16 outputs, window = the
 //     lane's last 64 samples, which sit in a four-slot ring in LDS (f16 hi / lo words, 128 bytes per column and

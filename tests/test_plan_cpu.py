@@ -21,7 +21,7 @@ def test_headline_shape():
     p = q(8192, 480000)
     assert p["layout"] == 7 and p["uses_seg"] == 1
     assert (p["head_frames"], p["body_fragments"], p["segments"], p["fragments_per_lane"]) == (0, 200, 8, 25)
-    assert p["warm_steps"] == 300                                   # 0.1 s of 16-frame steps, a multiple of 4
+    assert p["warm_steps"] == 228                                   # 0.075 s of 16-frame steps (225), rounded up to a multiple of 4
     assert p["n_tiles"] == 200 and p["n_fragments_ended"] == 200 and p["frames_left_after"] == 2400
     assert 8192 * p["segments"] == 65536                            # one lane per (stream, segment): 1024 waves, one per SIMD
 
@@ -36,7 +36,7 @@ def test_fragments_that_are_not_whole_steps_keep_their_read_ahead(fs):
     assert p["body_fragments"] == 199                               # 15 frames behind the body are one too few
     p = q(8192, 200 * fragm + 16, fs)
     assert p["body_fragments"] == 200
-    assert p["warm_steps"] % 4 == 0 and p["warm_steps"] * 16 >= 0.1 * fs
+    assert p["warm_steps"] % 4 == 0 and p["warm_steps"] * 16 >= 0.075 * fs
 
 
 def test_a_call_that_starts_inside_a_fragment():
