@@ -7,7 +7,8 @@
 #include "mtr_engine.h"
 
 #define MTR_FIR_HALO   47          /* 2*hl - 1 frames of history the 48-tap window needs */
-#define MTR_WARM_SEC   0.2f        /* K-filter warm-up for mid-stream segments: |lambda|^(0.2 fs) ~ 1e-21 */
+#define MTR_WARM_SEC   0.075f      /* K-filter warm-up for mid-stream segments of the wave-per-segment kernels, in whole tiles (two of ~2500
+                                    * frames at 48 kHz: |lambda|^4992 = 1.5e-11; see MTR_SEG_WARM_SEC.  Was 0.2 s = four tiles: 1e-21) */
 #ifndef MTR_SEG_WARM_SEC
 #define MTR_SEG_WARM_SEC 0.075f    /* the segments of the lane = segment kernel (layout 7): |lambda|^(0.075 fs) = 1.6e-8 of the state a segment
                                     * starts without — under f32's own resolution of it, 6e-8, which 0.0694 s reach (any rate: the slowest
