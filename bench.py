@@ -204,19 +204,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU path")
-    # MTR_BENCH_SHARED_GPU=1: every rank on GPU 0 with the gloo backend — a rehearsal of the N > 1 control
-    # flow on a one-GPU box (RCCL refuses two ranks on one device); never a measurement.
+    # MTR_BENCH_SHARED_GPU=1: every rank on GPU 0 — a rehearsal of the N > 1 control and reduction flow on a one-GPU box
+    # (RCCL refuses two ranks on one device, so the agreed fallback reduces); never a measurement.
     shared = os.environ.get("MTR_BENCH_SHARED_GPU") == "1"
     if shared:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        # torch.distributed is the CONTROL plane only (the 128-byte communicator id, barriers, the max over ranks of the
+        # clock): gloo on 127.0.0.1.  The job's one RCCL communicator is the engine's own (mtr_comm_init, below) — no second
+        # one is created beside it, so nothing can race its ncclCommInitRank on the same devices.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        dist.init_process_group("gloo")
 
     fs = args.fs
     S, T = args.streams, int(round(args.seconds * fs))
@@ -241,24 +241,54 @@ def main():
     eng = M.Engine(S, fs, meters, n_channels=1 if mono else 2, device=local, tune_run=args.run,
                    tune_segments=args.segments, tune_layout=args.layout, tune_fir=args.fir, tune_prune=args.prune)
     eng.integr_start()
-    # the job's communicator: RCCL behind the C ABI; on a shared-GPU rehearsal (gloo) the torch fallback reduces
-    comm, collective = None, "torch.distributed (gloo rehearsal)"
-    if not shared or os.environ.get("MTR_BENCH_TRY_RCCL") == "1":    # (the rehearsal can exercise the agreed fallback: RCCL refuses two ranks on one device)
+    # The job's communicator: RCCL behind the C ABI.  Every rank is past its allocations and its first kernels (a barrier on
+    # both sides of the collective ncclCommInitRank), and the ranks AGREE on how they reduce: one rank on a fallback would
+    # leave the others inside ncclAllReduce.  Fallbacks, in order: a torch.distributed NCCL (= RCCL) group, then gloo on
+    # the same device buffers (a host hop for 6 KB; what the shared-GPU rehearsal ends up with).
+    def agreed(ok):
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    comm, group, err = None, None, None
+    collective = "RCCL behind the C ABI (mtr_engine_reduce)"
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if shared and os.environ.get("MTR_BENCH_TRY_RCCL") != "1":
+        err = "not tried (MTR_BENCH_SHARED_GPU)"
+    else:
         try:
-            comm, collective, err = mdist.make_comm(rank, world, local), "RCCL behind the C ABI (mtr_engine_reduce)", None
-        except Exception as ex:                                   # noqa: BLE001 — reported below, never silent
+            comm = mdist.make_comm(rank, world, local)
+        except Exception as ex:                                   # noqa: BLE001 — reported in config.collective, never silent
             err = ex
-        if world > 1:
-            # every rank reduces the same way or none does: one rank on the fallback would leave the others in ncclAllReduce
-            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if comm is not None:
-                    comm.close()
-                comm, collective = None, "torch.distributed all_reduce (mtr_comm_init failed on a rank: %s)" % (err or "another rank")
-                print("bench.py: rank %d: %s" % (rank, collective), file=sys.stderr)
-        elif err:
-            raise err
+    if world == 1 and err:
+        raise err
+    if world > 1 and not agreed(err is None):
+        if comm is not None:
+            comm.close()
+            comm = None
+        why = "mtr_comm_init failed on a rank: %s" % (err or "another rank")
+        ok = False
+        if not shared:
+            try:
+                group = dist.new_group(backend="nccl")           # "nccl" is RCCL on ROCm
+                probe = torch.ones(1, dtype=torch.int32, device=dev)
+                dist.all_reduce(probe, group=group)
+                ok = int(probe.item()) == world
+            except Exception as ex:                               # noqa: BLE001
+                why += "; torch NCCL group: %r" % (ex,)
+            ok = agreed(ok)
+        if ok:
+            collective = "torch.distributed all_reduce over a NCCL (= RCCL) group (%s)" % why
+        else:
+            group = None
+            collective = "torch.distributed all_reduce over gloo, device buffers through the host (%s)" % why
+        print("bench.py: rank %d: %s" % (rank, collective), file=sys.stderr)
+    if world > 1:
+        dist.barrier()
 
     def step():
         if mono:
@@ -270,28 +300,41 @@ def main():
                 eng.reduce(comm, agg_hist.data_ptr(), agg_max.data_ptr(), stream)   # the only collective of the job (RCCL)
             else:
                 eng.aggregate_device(agg_hist.data_ptr(), agg_max.data_ptr(), stream)
-                mdist.all_reduce_aggregate(agg_hist, agg_max)
+                mdist.all_reduce_aggregate(agg_hist, agg_max, group)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     eng.timing_enable(True)
+    # per-step GPU time on the launching stream (the engine runs on torch's current stream here, so torch's events see it):
+    # the median beside the mean — the headline kernel is power-limited and its clock moves within a run
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         step()
+    marks[args.steps].record()
     torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0                              # this rank's own loop, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    per_call = eng.timing_calls()
+    tq = eng.timing_query()
+    my_kernel_ms = float(per_call[:, 0].sum() + per_call[:, 1].sum()) / max(len(per_call), 1)
+    ranks_ms = [[1e3 * t_own / args.steps, my_kernel_ms]]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    tq = eng.timing_query()
+        rows = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor(ranks_ms[0], dtype=torch.float64))
+        ranks_ms = [[float(v) for v in r] for r in rows]
 
     if rank == 0:
         frames_job = float(world) * S * T * args.steps
@@ -302,6 +345,8 @@ def main():
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
+            "ms_per_step_median": step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]),
+            "ms_per_step_min_max": [step_ms[0], step_ms[-1]],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -314,6 +359,14 @@ def main():
                        "frames_per_s": frames_job / dt, "parallelism": f"streams sharded x{world}",
                        "collective": collective},
         }
+        if world > 1:
+            # What the ranks did on their own: every rank's loop before it waited for the others, and the GPU time of
+            # its own kernels (fused + gate, HIP events).  `speedup_vs_ideal` = the job's rate over the rate N ranks would have
+            # if each ran at its own kernels' speed with no collective, no launch gaps and no skew between ranks.
+            out["per_rank_ms"] = [r[0] for r in ranks_ms]
+            out["per_rank_kernel_ms"] = [r[1] for r in ranks_ms]
+            ideal = sum(2.0 * S * T / (r[1] * 1e-3) for r in ranks_ms if r[1] > 0)
+            out["speedup_vs_ideal"] = (out["value"] / ideal) if ideal > 0 else None
         layout = eng.layout()
         if tq["calls"] and (meters & (M.METER_EBU | M.METER_TRUEPEAK)):
             k_ms = tq["ms_fused"] / tq["calls"]
@@ -322,6 +375,10 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(args.meters, S, T, layout),
                                "kernel": kname, "kernel_ms": k_ms, "gate_ms": tq["ms_gate"] / tq["calls"],
+                               "kernel_ms_median": float(np.median(per_call[:, 0])), "kernel_ms_min_max": [float(per_call[:, 0].min()), float(per_call[:, 0].max())],
+                               "frac_at_kernel_ms_median": S * T * BYTES_PER_FRAME / (float(np.median(per_call[:, 0])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               # the whole step (kernel + gate + aggregate + the RCCL reduce): what `value` is made of
+                               "whole_step_frac": S * T * BYTES_PER_FRAME / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_launch": S * T * BYTES_PER_FRAME}
             if layout in (6, 7):
                 seg = layout == 7 and eng.seg_stats()[0] > 0

@@ -229,6 +229,10 @@ int  mtr_engine_timing_enable (mtr_engine* e, int on);
 /* Sum over the process calls since the last query: fused K-weight+true-peak kernel, gating kernel,
  * filter-bank kernel (ms) and the number of calls. Synchronises. */
 int  mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, float* ms_bank, uint32_t* calls);
+/* The same per call, without resetting anything: out [min (calls, cap)][4] = fused, gate, everything behind the gate (bank,
+ * integer paths, history), and the whole call from its first to its last event (ms); *calls = timed calls since the last
+ * query.  For the median beside the mean (a power-limited kernel drifts within a run).  Synchronises. */
+int  mtr_engine_timing_calls (mtr_engine* e, float* out, uint32_t cap, uint32_t* calls);
 /* With tune_prune: interpolator tile passes considered / skipped since the engine was created. */
 int  mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped);
 /* With tune_prune = 2 (layout 6): 256-frame channel-blocks screened with the first of the three products / completed

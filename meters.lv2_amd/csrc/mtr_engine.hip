@@ -1348,6 +1348,21 @@ int mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, flo
 	return MTR_OK;
 }
 
+int mtr_engine_timing_calls (mtr_engine* e, float* out, uint32_t cap, uint32_t* calls)
+{
+	if (!e || (!out && cap)) return fail (MTR_ERR_ARG, "mtr_engine_timing_calls: null argument");
+	int rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	if (calls) *calls = e->timed_calls;
+	for (uint32_t i = 0; i < e->timed_calls && i < cap; ++i) {
+		float* o = out + (size_t) i * 4;
+		for (int k = 0; k < 3; ++k)
+			if (hipEventElapsedTime (&o[k], e->ev[i * 4 + k], e->ev[i * 4 + k + 1]) != hipSuccess) o[k] = 0.f;
+		if (hipEventElapsedTime (&o[3], e->ev[i * 4], e->ev[i * 4 + 3]) != hipSuccess) o[3] = 0.f;
+	}
+	return MTR_OK;
+}
+
 int mtr_synth_fill_device (float* d_audio, uint32_t n_streams, uint64_t n_frames, uint64_t stride,
                            uint32_t seed, float fs, int kind, void* hip_stream)
 {

@@ -124,6 +124,7 @@ def _load():
     L.mtr_hist_loudness.restype = None
     L.mtr_engine_timing_enable.argtypes = [vp, C.c_int]
     L.mtr_engine_timing_query.argtypes = [vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(u32)]
+    L.mtr_engine_timing_calls.argtypes = [vp, vp, u32, C.POINTER(u32)]
     L.mtr_kweight_coef.argtypes = [f32, vp]
     L.mtr_fir_table.argtypes = [vp]
     L.mtr_band_coef.argtypes = [C.c_double, u32, vp]
@@ -389,6 +390,13 @@ class Engine:
 
     def timing_enable(self, on=True):
         _check(lib.mtr_engine_timing_enable(self._h, int(on)), "timing_enable")
+
+    def timing_calls(self, cap=4096):
+        """[calls, 4] float32 ms per timed call since the last query: fused, gate, behind the gate, whole call."""
+        n = C.c_uint32()
+        out = np.zeros((cap, 4), np.float32)
+        _check(lib.mtr_engine_timing_calls(self._h, out.ctypes.data, cap, C.byref(n)), "timing_calls")
+        return out[:min(n.value, cap)]
 
     def timing_query(self):
         f, g, b, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint32()
