@@ -166,8 +166,9 @@ int  mtr_engine_bitstats (mtr_engine* e, uint32_t first, uint32_t count,
                           int32_t* hist, int32_t* counters, float* minmax);
 /* replaces: the state sdh_run's loop maintains (src/sigdistlv2.c:296-327): bins [count][361],
  *   peak [count][2] = {count, bin}, moments [count][3] = {sum, mean, M2} (double), n [count].
- *   mean / M2 are the Welford moments of the BINNED samples: the reference's once a sample fell outside the 361
- *   bins divides by the index among all samples (:312-315) and stops being a mean — that quirk is not mirrored;
+ *   mean / M2 are the reference's accumulators hist_tmpS / hist_varS: Welford's moments while every sample is binned,
+ *   and — once a sample fell outside the 361 bins, after which the reference keeps dividing by the index among ALL
+ *   samples (:312-315) and they stop being moments — the very numbers it then reports (1e-12 relative; mtr_intstat.hip);
  *   bins, peak, n and sum are bit-identical in every case. */
 int  mtr_engine_sigdist (mtr_engine* e, uint32_t first, uint32_t count,
                          int32_t* bins, int32_t* peak, double* moments, int64_t* n);

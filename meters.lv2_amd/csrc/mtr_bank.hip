@@ -96,8 +96,16 @@ __global__ __launch_bounds__ (64) void k_bank (const mtr_bank_args a)
 			}
 	};
 
+	// the staged chunk is written by all lanes and read by others: a workgroup-scope release / acquire around a wave barrier
+	// makes that hand-over explicit (one wave: no cost but a wait for the LDS writes; ADVICE r3 — in-order LDS alone is not a contract)
+	auto handover = [] () {
+		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier ();
+		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+	};
 	fetch (0);
 	stage (0, 0);
+	handover ();
 	fetch (BANK_CHUNK);
 	int buf = 0;
 	for (uint64_t base = 0; base < a.n_frames; base += BANK_CHUNK, buf ^= 1) {
@@ -105,7 +113,9 @@ __global__ __launch_bounds__ (64) void k_bank (const mtr_bank_args a)
 		// the next chunk into the other buffer (its previous readers are behind us in this wave's own instruction stream),
 		// the one after it into the registers: both land under this chunk's arithmetic
 		if (base + BANK_CHUNK < a.n_frames) {
+			handover ();                                  // (the other buffer's readers of the chunk before are done)
 			stage (buf ^ 1, base + BANK_CHUNK);
+			handover ();
 			fetch (base + 2 * BANK_CHUNK);
 		}
 		const double* const my = &mix[buf][row][0];

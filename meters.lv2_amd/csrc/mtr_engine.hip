@@ -16,7 +16,6 @@
 #include <vector>
 
 #include "mtr_internal.h"
-#include "mtr_mfma_fir.h"
 #include "mtr_mfma16_fir.h"
 
 static thread_local std::string g_err;
@@ -656,12 +655,17 @@ static SegPlan seg_plan (const PlanCtx* e, const float* d_audio, uint64_t N, uin
 	if (gmax < 1) gmax = 1;
 	if (e->cfg.tune_segments) gmax = std::min<uint64_t> (gmax, e->cfg.tune_segments);
 	const uint64_t g0 = e->cfg.tune_segments ? gmax : 1;
+	// Candidates: for a given number of tiles per lane n = ceil (tiles / g) the smallest g has the fewest rounds, so only the g
+	// at which n changes are evaluated — O (sqrt (tiles)) of them instead of every g up to 65536 (this runs on every process
+	// call, in the caller's thread: one stream x one hour cost 0.17 ms here before it was told to take k_kwtp16).
 	double best = 0; uint64_t bg = 0;
-	for (uint64_t g = g0; g <= gmax && g <= 65536; ++g) {
+	for (uint64_t g = g0; g <= gmax && g <= 65536; ) {
 		const uint64_t waves = (S * g + 63) / 64, rounds = (waves + e->seg_slots - 1) / e->seg_slots;
 		const uint64_t n_main = tiles / g + (tiles % g ? 1 : 0);
 		const double t = (double) rounds * ((double) n_main * spt + (g > 1 ? 0.3 * warm_steps : 0.0));
 		if (!bg || t < best) { best = t; bg = g; }
+		if (n_main <= 1) break;
+		g = std::max<uint64_t> (g + 1, (tiles + n_main - 2) / (n_main - 1));      // the smallest g with fewer tiles per lane
 	}
 	const double t6 = 1.2 * (double) S * (double) tiles * spt / (64.0 * e->seg_slots);
 	if (!e->cfg.tune_segments && best > t6) return sp;
@@ -1258,6 +1262,7 @@ int mtr_engine_layout (const mtr_engine* e) { return e ? (e->seg_ok ? 7 : e->lay
 int mtr_plan_query (const mtr_config* cfg, uint32_t frames_left_in_fragment, uint64_t n_frames, uint32_t n_slots, mtr_plan_info* out)
 {
 	if (!cfg || !out) return fail (MTR_ERR_ARG, "null argument");
+	if (cfg->struct_size != sizeof (mtr_config)) return fail (MTR_ERR_ARG, "mtr_plan_query: bad config (struct_size)");
 	if (cfg->n_streams == 0 || !(cfg->sample_rate >= 1000.0f) || n_frames == 0 || n_frames > 0xffffffffull) return fail (MTR_ERR_ARG, "mtr_plan_query: streams, rate or frames out of range");
 	PlanCtx c;
 	c.cfg = *cfg;

@@ -192,8 +192,10 @@ __global__ __launch_bounds__ (64, 2) void k_kwtp16 (const mtr_fused_args a)
 				for (int n = 0; n < K; ++n) if (n < lim) { il = fmaxf (il, fabsf (x[n].x)); ir = fmaxf (ir, fabsf (x[n].y)); }
 			}
 			if (q == 0 && jj == 0 && lane >= HALO / 4 && lane < HALO / 2) {
-				// positions 24..47 <-> frames -24..-1; position p counts while frame p - 48 < n_frames - 24
-				const int64_t plim = (int64_t) a.n_frames + 24;
+				// positions 24..47 <-> frames t0 - 24 .. t0 - 1; position p counts while frame t0 + p - 48 < n_frames - 24 (t0 = 0
+				// unless this launch finishes a call behind the lane = segment kernel: a tail shorter than 24 frames leaves
+				// the last frames in front of it to the next call, as k_seg's p0_end does — ADVICE r3)
+				const int64_t plim = (int64_t) a.n_frames + 24 - t0;
 				if (2 * lane < plim)     { il = fmaxf (il, fabsf (ph0.x)); ir = fmaxf (ir, fabsf (ph0.y)); }
 				if (2 * lane + 1 < plim) { il = fmaxf (il, fabsf (ph1.x)); ir = fmaxf (ir, fabsf (ph1.y)); }
 			}

@@ -57,8 +57,9 @@ struct mtr_fused_args {
 	float           gain_l, gain_r;
 };
 
-/* Arguments of the lane = time segment kernel (mtr_seg.hip, layout 7).  The launch covers the tiles [0, n_body) of a call
- * that starts on a fragment boundary; every tile is tile_frames long (a multiple of MTR_SEG_STEP).  Segment q of a stream
+/* Arguments of the lane = time segment kernel (mtr_seg.hip, layout 7).  The launch covers the whole fragments of a call,
+ * from `head` frames into it (the rest of a fragment the call started in, k_kwtp16's); every tile is tile_frames long — any
+ * length of at least four steps: a tile that is not a multiple of MTR_SEG_STEP ends inside a step.  Segment q of a stream
  * answers for seg_base + (q < seg_rem) consecutive tiles, and every lane processes n_main = seg_base + (seg_rem > 0) of
  * them, starting one tile early where its own segment is the shorter kind. */
 #define MTR_SEG_STEP 16            /* frames per lane and step: one column of the block-Toeplitz product */

@@ -321,14 +321,15 @@ def test_full_size_properties(M, oracle, fs):
     buf = torch.empty((S, T, 2), dtype=torch.float32, device="cuda")
     M.synth_fill_device(buf.data_ptr(), S, T, T, 777, fs, 1)
     torch.cuda.synchronize()
-    pick = [0, 1, S // 2 + 3, S - 1]
+    pick = sorted({0, 1, S // 2 + 3, S - 1} | {(S * k) // 31 + (7 * k) % 13 for k in range(1, 31)})   # 34 streams: both ends, every wave position
+    mid = S // 2 + 3
 
     def run(ptr):
         with M.Engine(S, fs, M.METER_EBU | M.METER_TRUEPEAK) as e:
             e.integr_start()
             e.process_device(ptr, T)
             hm, hs = e.histograms()
-            return e.out9(), e.truepeak(), hm, hs, e.fragment_powers(pick[2], 1)
+            return e.out9(), e.truepeak(), hm, hs, e.fragment_powers(mid, 1)
 
     a = run(buf.data_ptr())
     b = run(buf.data_ptr())
@@ -340,7 +341,7 @@ def test_full_size_properties(M, oracle, fs):
         assert np.allclose(a[0][s, :4], o["out9"][:4], atol=DB_TOL), s
         assert abs(a[0][s, 4] - o["out9"][4]) <= CONTRACT_DB
         assert np.allclose(a[1][s], oracle.tp(host[s], fs, 8192), rtol=2e-6), s
-        assert np.abs(a[2][s] - o["hist_M"]).sum() // 2 <= MOVED_MAX
+        assert np.abs(a[2][s] - o["hist_M"]).sum() // 2 <= MOVED_MAX and np.abs(a[3][s] - o["hist_S"]).sum() // 2 <= MOVED_MAX
     assert a[2].sum() == S * 100 and a[3].sum() == S * 20    # every stream: 100 M points, 20 S points
     buf.mul_(2.0)
     torch.cuda.synchronize()
@@ -478,7 +479,8 @@ def test_truepeak_ballistics_full_size_properties(M, oracle):
     a = run(buf.data_ptr())
     assert np.array_equal(a, run(buf.data_ptr()))                       # deterministic
     assert np.all(a > 0) and np.all(a[:, :2] < 20.0)
-    pick = [0, 1, S // 2 + 3, S - 1]
+    pick = sorted({0, 1, S // 2 + 3, S - 1} | {(S * k) // 31 + (7 * k) % 13 for k in range(1, 31)})   # 34 streams: both ends, every wave position
+    mid = S // 2 + 3
     for s in pick:
         xs = buf[s].cpu().numpy()
         for c in range(2):
@@ -520,7 +522,8 @@ def test_filter_bank_full_size_properties(M, oracle):
     v, db = run(buf.data_ptr())
     v2, db2 = run(buf.data_ptr())
     assert np.array_equal(v, v2) and np.array_equal(db, db2)            # deterministic
-    pick = [0, 1, S // 2 + 3, S - 1]
+    pick = sorted({0, 1, S // 2 + 3, S - 1} | {(S * k) // 31 + (7 * k) % 13 for k in range(1, 31)})   # 34 streams: both ends, every wave position
+    mid = S // 2 + 3
     for s in pick:
         o = oracle.spectr(buf[s].cpu().numpy(), fs, T)
         assert np.allclose(v[s], o["val"], rtol=1e-4), s
