@@ -80,6 +80,37 @@ def cpu_baseline(host_audio, fs, budget_s=12.0):
     return out
 
 
+def end_to_end_host(M, torch, buf, fs, meters, device, n=1024, reps=3):
+    """Host-resident audio: n streams of the benchmark's own buffers in pageable memory -> mtr_engine_process_host."""
+    T = buf.shape[1]
+    x = buf[:n].cpu().numpy()
+    dst = torch.empty_like(buf[:n])
+    src = torch.from_numpy(x)
+    dst.copy_(src); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    h2d = x.nbytes * reps / (time.perf_counter() - t0)
+    del dst
+    with M.Engine(n, fs, meters, device=device) as e:
+        e.integr_start()
+        e.process(x); e.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e.process(x)
+        e.sync()
+        dt = (time.perf_counter() - t0) / reps
+        e.timing_enable(True)
+        e.process(x)
+        q = e.timing_query()
+    return {"GB_per_s": x.nbytes / dt / 1e9, "frames_per_s": n * T / dt, "samples_per_s": 2.0 * n * T / dt,
+            "plain_h2d_GB_per_s": h2d / 1e9, "frac_of_pcie": (x.nbytes / dt) / h2d,
+            "chunks": q["calls"], "kernel_ms_total": q["ms_fused"] + q["ms_gate"], "wall_ms": dt * 1e3,
+            "sample": f"{n} streams x {T / fs:.0f} s = {x.nbytes / 1e9:.2f} GB of pageable host memory, {reps} passes; "
+                      "256 MiB chunks of streams, the copy of chunk k + 1 under the kernels of chunk k"}
+
+
 def kernel_sha():
     """Hash of the sources of the dominant kernel — and of the header that fixes how much of a stream its segments re-read
     for their warm-up: the committed PMC traffic figure is valid for exactly this code."""
@@ -561,6 +592,13 @@ def main():
                 "bound": "the busiest SIMD pair of a workgroup (four blocks of matrix-pipe products + per-frame max-affine maps on three SIMDs beside "
                          "the serial chains: 3 dependent operations per frame and channel; DESIGN.md 3.5)"}
             extra["configs"] = cfgs
+            # SURVEY.md 8d "Timing": the end-to-end figure of a host whose audio is NOT resident — pageable host memory through
+            # mtr_engine_process_host (chunks of streams: chunk k + 1 crosses the link under the kernels of chunk k) — next to a
+            # plain copy of the same bytes from the same memory.  Never `value`.
+            try:
+                extra["end_to_end_host"] = end_to_end_host(M, torch, buf, fs, meters, local)
+            except Exception as exc:                              # never let a context figure break the benchmark line
+                extra["end_to_end_host"] = {"error": repr(exc)}
             try:
                 from _lv2host import Host
                 from _lv2lat import run_latency

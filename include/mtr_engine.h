@@ -130,9 +130,15 @@ int  mtr_engine_spectr_reset_peak (mtr_engine* e);
  * spectrum_run (src/spectrumlv2.c:210-227), TruePeakdsp::process (src/meters.cc:465-475). */
 int  mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_frames,
                                 uint64_t stream_stride_frames, void* hip_stream);
-/* Same with HOST memory (copied to the device first; PCIe-bound, not the benchmarked path). */
+/* Same with HOST memory: the batch crosses the host link in chunks of streams (results are per stream, so chunking is
+ * exact — bit for bit what mtr_engine_process_device gives on the same audio), chunk k + 1 on a copy stream under the kernels
+ * of chunk k, through two device buffers of one chunk each.  Host-link-bound: end to end at the link's rate (bench.py
+ * reports it as extra.end_to_end_host, never as `value`).  Returns when the caller's memory has been read; the kernels
+ * may still run (mtr_engine_sync / the result getters wait). */
 int  mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_frames,
                               uint64_t stream_stride_frames);
+/* Bytes of audio per chunk of mtr_engine_process_host (0 = the default, 256 MiB; at least one stream per chunk). */
+int  mtr_engine_set_host_chunk_bytes (mtr_engine* e, uint64_t bytes);
 /* n_streams == 1, planar host channels — the shape an LV2 run() hands over
  * (src/meters.cc:298-299: one float* per port, n_samples frames). */
 int  mtr_engine_process_planar_host (mtr_engine* e, const float* const* channels, uint32_t n_frames);

@@ -142,6 +142,14 @@ struct mtr_engine {
 	Plan             plan;
 	uint32_t         last_n_frag = 0;
 
+	// A process call may cover a VIEW of the batch: streams [v_off, v_off + v_cnt) (v_cnt = 0: all of them).  The chunked host
+	// path (mtr_engine_process_host) walks the batch view by view — every per-stream array is indexed from v_off, the host-side
+	// cursors (fragment phase, ping-pong indices, open DR-14 window) move when the last view has been queued.
+	uint32_t v_off = 0, v_cnt = 0;
+	size_t           host_chunk_bytes = (size_t) 256 << 20;
+	hipStream_t      copy_stream = nullptr;
+	hipEvent_t       ev_copied[2] = { nullptr, nullptr }, ev_computed[2] = { nullptr, nullptr };
+
 	bool timing = false;
 	std::vector<hipEvent_t> ev;     // groups of 4: start, after fused, after gate, after bank
 	uint32_t timed_calls = 0;
@@ -390,6 +398,8 @@ void mtr_engine_destroy (mtr_engine* e)
 	for (PlanSlot& ps : e->plan_slot) { ps.dev.release (); ps.pin.release (); if (ps.done) (void) hipEventDestroy (ps.done); }
 	e->pin_in.release (); e->pin_state.release (); e->pin_bank.release ();
 	if (e->own_stream) (void) hipStreamDestroy (e->own_stream);
+	if (e->copy_stream) (void) hipStreamDestroy (e->copy_stream);
+	for (int b = 0; b < 2; ++b) { if (e->ev_copied[b]) (void) hipEventDestroy (e->ev_copied[b]); if (e->ev_computed[b]) (void) hipEventDestroy (e->ev_computed[b]); }
 	if (e->xs_event) (void) hipEventDestroy (e->xs_event);
 	e->bank_coef.release (); e->bank_z.release (); e->bank_val.release (); e->bank_max.release (); e->bank_ac[0].release (); e->bank_ac[1].release ();
 	e->fir_g.release (); e->m16_a.release ();
@@ -829,7 +839,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	e->last_stream = st;
 	e->queued = true;
 	e->snap_valid = false;
-	const uint32_t S = e->cfg.n_streams;
+	const uint32_t S = e->v_cnt ? e->v_cnt : e->cfg.n_streams;     // the streams of this call's view ...
+	const size_t vo = e->v_cnt ? e->v_off : 0;                       // ... and where they start in every per-stream array
 	const bool ebu = e->cfg.meters & MTR_METER_EBU, tp = e->cfg.meters & MTR_METER_TRUEPEAK;
 	const bool bank = e->cfg.meters & MTR_METER_SPECTR30;
 
@@ -845,9 +856,9 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		const Plan& pl = e->plan;
 		mtr_fused_args fa;
 		fa.audio = d_audio; fa.stride = stride;
-		fa.hist = e->fir_hist[e->hist_cur].p;
+		fa.hist = e->fir_hist[e->hist_cur].p + vo * MTR_FIR_HALO * 2;
 		fa.tile_start = e->tile_start; fa.seg_tile = e->seg_tile; fa.scan_m = e->scan_m.p;
-		fa.state = e->state.p; fa.tile_power = e->tile_power.p;
+		fa.state = e->state.p + vo; fa.tile_power = e->tile_power.p + vo * pl.n_tiles;
 		fa.n_streams = S; fa.n_segs = pl.n_segs; fa.n_tiles = pl.n_tiles;
 		fa.warm_tiles = (uint32_t) std::ceil (MTR_WARM_SEC * e->cfg.sample_rate / (float) (64 * e->run));
 		fa.a0 = e->kw[0]; fa.a1 = e->kw[1]; fa.a2 = e->kw[2]; fa.b1 = e->kw[3]; fa.b2 = e->kw[4];
@@ -870,7 +881,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 				lrc = mtr_launch_kwtp16 (e->run, ebu, fa, S, st);
 			}
 			mtr_seg_args sa;
-			sa.audio = d_audio; sa.stride = stride; sa.hist = fa.hist; sa.state = e->state.p; sa.tile_power = e->tile_power.p;
+			sa.audio = d_audio; sa.stride = stride; sa.hist = fa.hist; sa.state = fa.state; sa.tile_power = fa.tile_power;
 			sa.head = sp.head; sa.tile0 = pl.head_tiles;
 			sa.mfma_a = e->m16_a.p;
 			sa.n_streams = S; sa.n_segs = sp.n_segs; sa.n_tiles = pl.n_tiles; sa.tile_frames = e->fragm;
@@ -894,12 +905,12 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 		mtr_gate_args ga;
-		ga.state = e->state.p; ga.hist = e->hist.p; ga.tile_power = e->tile_power.p;
-		ga.frag_tile = e->frag_tile; ga.frag_power = e->frag_power.p; ga.bin_power = e->bin_power.p;
+		ga.state = e->state.p + vo; ga.hist = e->hist.p + vo * 2 * MTR_HIST_LEN; ga.tile_power = fa.tile_power;
+		ga.frag_tile = e->frag_tile; ga.frag_power = e->frag_power.p + vo * pl.n_frag; ga.bin_power = e->bin_power.p;
 		ga.n_streams = S; ga.n_tiles = ebu ? pl.n_tiles : 0; ga.n_frag = ebu ? pl.n_frag : 0;
 		ga.tail_tile = ebu ? pl.tail_tile : 0;
 		ga.fragm = (float) e->fragm; ga.integr = e->integr ? 1 : 0;
-		ga.max_scratch = e->gate_max.p;
+		ga.max_scratch = e->gate_max.p + vo * 2;
 		if (mtr_launch_gate (ga, st)) { plan_abort (e, st); return fail (MTR_ERR_HIP, "k_gate launch"); }
 		{
 			PlanSlot& ps = e->plan_slot[e->plan_cur];                 // k_gate is the plan's last reader
@@ -916,7 +927,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (bank) {
 		mtr_bank_args ba;
 		ba.audio = d_audio; ba.stride = stride; ba.n_frames = n_frames;
-		ba.coef = e->bank_coef.p; ba.z = e->bank_z.p; ba.val = e->bank_val.p; ba.mx = e->bank_max.p; ba.ac_in = e->bank_ac[e->bank_ac_cur].p; ba.ac_out = e->bank_ac[e->bank_ac_cur ^ 1].p;
+		ba.coef = e->bank_coef.p; ba.z = e->bank_z.p + vo * MTR_NBANDS * 12; ba.val = e->bank_val.p + vo * MTR_NBANDS; ba.mx = e->bank_max.p + vo * MTR_NBANDS;
+		ba.ac_in = e->bank_ac[e->bank_ac_cur].p + vo; ba.ac_out = e->bank_ac[e->bank_ac_cur ^ 1].p + vo;
 		ba.n_streams = S; ba.n_channels = e->cfg.n_channels; ba.omega = e->omega;
 		if (mtr_launch_bank (ba, st)) return fail (MTR_ERR_HIP, "k_bank launch");
 		e->bank_ac_cur ^= 1;
@@ -924,9 +936,9 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	// (the integer tables are int32, as the reference's, which stops counting at 2^31 - 1 samples; the kernels index
 	// a call's samples with 32 bits: checked on entry)
 	if (e->cfg.meters & MTR_METER_BITSTATS)
-		if (mtr_launch_bitstats (d_audio, stride, n_frames, e->bim.p, S, st)) return fail (MTR_ERR_HIP, "k_bitstats launch");
+		if (mtr_launch_bitstats (d_audio, stride, n_frames, e->bim.p + vo, S, st)) return fail (MTR_ERR_HIP, "k_bitstats launch");
 	if (e->cfg.meters & MTR_METER_SIGDIST)
-		if (mtr_launch_sigdist (d_audio, stride, n_frames, e->sdh.p, S, st)) return fail (MTR_ERR_HIP, "k_sigdist launch");
+		if (mtr_launch_sigdist (d_audio, stride, n_frames, e->sdh.p + vo, S, st)) return fail (MTR_ERR_HIP, "k_sigdist launch");
 	if (e->cfg.meters & MTR_METER_DR14) {
 		mtr_dr14_args da;
 		da.audio = d_audio; da.stride = stride; da.n_frames = n_frames;
@@ -936,9 +948,10 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		da.n_windows = (uint32_t) (tot / da.window);
 		da.n_pieces = da.n_windows + (tot % da.window ? 1 : 0);
 		da.n_streams = S; da.n_channels = e->cfg.n_channels;
-		if (e->dr_sum.reserve ((size_t) S * da.n_pieces * 2) || e->dr_peak.reserve ((size_t) S * da.n_pieces * 2))
+		if (e->dr_sum.reserve ((size_t) e->cfg.n_streams * da.n_pieces * 2) || e->dr_peak.reserve ((size_t) e->cfg.n_streams * da.n_pieces * 2))
 			return fail (MTR_ERR_NOMEM, "hipMalloc DR14 pieces");
-		da.state = e->dr_state.p; da.hist = e->dr_hist.p; da.piece_sum = e->dr_sum.p; da.piece_peak = e->dr_peak.p;
+		da.state = e->dr_state.p + vo; da.hist = e->dr_hist.p + vo * e->cfg.n_channels * MTR_DR_HISTBINS;
+		da.piece_sum = e->dr_sum.p + vo * da.n_pieces * 2; da.piece_peak = e->dr_peak.p + vo * da.n_pieces * 2;
 		if (mtr_launch_dr14 (da, st)) return fail (MTR_ERR_HIP, "k_dr14 launch");
 		e->dr_scnt = tot % da.window;
 	}
@@ -955,17 +968,17 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ka.hold = (int32_t) (0.5f * e->cfg.sample_rate + 0.5f);             // :51
 		ka.omega = 9.72f / e->cfg.sample_rate;
 		memcpy (ka.pw1, e->km_pw1, sizeof (ka.pw1));
-		ka.state = e->km_state.p;
-		if (e->km_piece.reserve ((size_t) S * std::max<uint32_t> (ka.n_pieces, 1) * 4) || e->km_max.reserve ((size_t) S * std::max<uint32_t> (ka.n_pieces, 1) * 2))
+		ka.state = e->km_state.p + vo * 2;
+		if (e->km_piece.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (ka.n_pieces, 1) * 4) || e->km_max.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (ka.n_pieces, 1) * 2))
 			return fail (MTR_ERR_NOMEM, "hipMalloc KMETER pieces");
-		ka.piece_state = e->km_piece.p; ka.piece_max = e->km_max.p;
+		ka.piece_state = e->km_piece.p + vo * ka.n_pieces * 4; ka.piece_max = e->km_max.p + vo * ka.n_pieces * 2;
 		if (mtr_launch_kmeter (ka, st)) return fail (MTR_ERR_HIP, "k_kmeter launch");
 	}
 	const bool tpb = e->cfg.meters & MTR_METER_TPBALLIST;
 	if (tpb) {
 		mtr_tpb_args ta;
 		ta.audio = d_audio; ta.stride = stride; ta.n_frames = n_frames;
-		ta.hist = e->fir_hist[e->hist_cur].p; ta.mfma_a = e->m16_a.p; ta.state = e->state.p;
+		ta.hist = e->fir_hist[e->hist_cur].p + vo * MTR_FIR_HALO * 2; ta.mfma_a = e->m16_a.p; ta.state = e->state.p + vo;
 		ta.n_streams = S; ta.n_channels = e->cfg.n_channels;
 		ta.w1 = e->tpb_w[0]; ta.w2 = e->tpb_w[1]; ta.w3 = e->tpb_w[2]; ta.g = e->tpb_w[3];
 		if (mtr_launch_tpb (ta, st)) return fail (MTR_ERR_HIP, "k_tpb launch");
@@ -973,8 +986,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (tp || tpb) {
 		// the 47 frames before the next call; after every consumer of the current history
 		const int hrc = e->cfg.n_channels == 2
-			? mtr_launch_history (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p, e->fir_hist[e->hist_cur ^ 1].p, S, st)
-			: mtr_launch_history_mono (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p, e->fir_hist[e->hist_cur ^ 1].p, S, st);
+			? mtr_launch_history (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p + vo * MTR_FIR_HALO * 2, e->fir_hist[e->hist_cur ^ 1].p + vo * MTR_FIR_HALO * 2, S, st)
+			: mtr_launch_history_mono (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p + vo * MTR_FIR_HALO * 2, e->fir_hist[e->hist_cur ^ 1].p + vo * MTR_FIR_HALO * 2, S, st);
 		if (hrc) return fail (MTR_ERR_HIP, "k_history launch");
 		e->hist_cur ^= 1;
 	}
@@ -992,6 +1005,35 @@ static int host_stream (mtr_engine* e, hipStream_t* st)
 	return MTR_OK;
 }
 
+// One view of the batch through mtr_engine_process_device; the host-side cursors move only with the last one.
+static int process_view (mtr_engine* e, const float* d_audio, uint64_t n_frames, uint64_t stride, hipStream_t st,
+                         uint32_t off, uint32_t cnt, bool last)
+{
+	const uint32_t frcnt = e->frcnt;
+	const int hist_cur = e->hist_cur, ac_cur = e->bank_ac_cur;
+	const uint64_t dr_scnt = e->dr_scnt, seg_calls = e->seg_calls, seg_frames = e->seg_frames;
+	e->v_off = off; e->v_cnt = cnt;
+	const int rc = mtr_engine_process_device (e, d_audio, n_frames, stride, st);
+	e->v_off = 0; e->v_cnt = 0;
+	if (rc || !last) {
+		e->frcnt = frcnt; e->hist_cur = hist_cur; e->bank_ac_cur = ac_cur; e->dr_scnt = dr_scnt;
+		e->seg_calls = seg_calls; e->seg_frames = seg_frames;
+	}
+	return rc;
+}
+
+int mtr_engine_set_host_chunk_bytes (mtr_engine* e, uint64_t bytes)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	e->host_chunk_bytes = bytes ? (size_t) bytes : (size_t) 256 << 20;
+	return MTR_OK;
+}
+
+// Host memory in, CHUNKED by streams (results are per stream: chunking is exact, and the routing of a call — which kernel,
+// how many time segments — is decided for the whole batch, so every stream sees the arithmetic it would see resident):
+// chunk k + 1 crosses the host link on a copy stream while the kernels of chunk k run on the engine's own; two device
+// buffers of one chunk each instead of a copy of the whole batch.  End to end the call runs at the link's rate
+// (bench.py: extra.end_to_end_host).
 int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_frames, uint64_t stride)
 {
 	if (!e || !h_audio) return fail (MTR_ERR_ARG, "mtr_engine_process_host: null argument");
@@ -999,21 +1041,42 @@ int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_fra
 	if (stride < n_frames) return fail (MTR_ERR_ARG, "stream_stride_frames < n_frames");
 	HIPCHK (hipSetDevice (e->cfg.device));
 	const size_t C = e->cfg.n_channels;
-	// (streams start on 16 bytes in the staging buffer: an even stride, so that every layout can take the call)
+	const uint32_t S = e->cfg.n_streams;
+	// (streams start on 16 bytes in the staging buffers: an even stride, so that every layout can take the call)
 	const uint64_t dstride = (n_frames + 1) & ~(uint64_t) 1;
-	const size_t total = (size_t) e->cfg.n_streams * dstride * C;
+	const size_t row = (size_t) dstride * C;                                  // floats per staged stream
+	uint32_t cs = (uint32_t) std::min<uint64_t> (S, std::max<uint64_t> (1, e->host_chunk_bytes / (row * sizeof (float))));
+	const uint32_t n_chunks = (S + cs - 1) / cs;
+	cs = (S + n_chunks - 1) / n_chunks;                                         // even chunks
+	const size_t buf_floats = ((size_t) cs * row + 63) & ~(size_t) 63;         // the second buffer starts on 256 bytes
 	hipStream_t st;
 	int rc = host_stream (e, &st);
 	if (rc) return rc;
-	// the staging buffer may still be read by the previous call (on whatever stream that ran)
+	if (!e->copy_stream) HIPCHK (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
+	for (int b = 0; b < 2; ++b) {
+		if (!e->ev_copied[b]) HIPCHK (hipEventCreateWithFlags (&e->ev_copied[b], hipEventDisableTiming));
+		if (!e->ev_computed[b]) HIPCHK (hipEventCreateWithFlags (&e->ev_computed[b], hipEventDisableTiming));
+	}
+	// the staging buffers may still be read by the previous call (on whatever stream that ran)
 	HIPCHK (hipStreamSynchronize (e->last_stream));
-	if (e->stage.reserve (total)) return fail (MTR_ERR_NOMEM, "hipMalloc staging buffer");
-	HIPCHK (hipMemcpy2DAsync (e->stage.p, dstride * C * sizeof (float), h_audio, stride * C * sizeof (float),
-	                          n_frames * C * sizeof (float), e->cfg.n_streams, hipMemcpyHostToDevice, st));
-	// The source is pageable caller memory and the copy is truly asynchronous: the caller may free
-	// or reuse it as soon as we return, so wait for the copy (not for the kernels) here.
-	HIPCHK (hipStreamSynchronize (st));
-	return mtr_engine_process_device (e, e->stage.p, n_frames, dstride, st);
+	if (e->stage.reserve (buf_floats * (n_chunks > 1 ? 2 : 1))) return fail (MTR_ERR_NOMEM, "hipMalloc staging buffers");
+	for (uint32_t k = 0, off = 0; k < n_chunks; ++k, off += cs) {
+		const uint32_t cnt = std::min (cs, S - off);
+		const int b = (int) (k & 1);
+		float* const dst = e->stage.p + (size_t) b * buf_floats;
+		if (k >= 2) HIPCHK (hipStreamWaitEvent (e->copy_stream, e->ev_computed[b], 0));   // the kernels of chunk k - 2 have read this buffer
+		HIPCHK (hipMemcpy2DAsync (dst, row * sizeof (float), h_audio + (size_t) off * stride * C, stride * C * sizeof (float),
+		                          n_frames * C * sizeof (float), cnt, hipMemcpyHostToDevice, e->copy_stream));
+		HIPCHK (hipEventRecord (e->ev_copied[b], e->copy_stream));
+		HIPCHK (hipStreamWaitEvent (st, e->ev_copied[b], 0));
+		rc = process_view (e, dst, n_frames, dstride, st, off, cnt, k + 1 == n_chunks);
+		if (rc) { (void) hipStreamSynchronize (e->copy_stream); return rc; }
+		HIPCHK (hipEventRecord (e->ev_computed[b], st));
+	}
+	// The source is pageable caller memory and the copies are truly asynchronous: the caller may free or reuse it as soon
+	// as we return, so wait for the copies (not for the kernels) here.
+	HIPCHK (hipStreamSynchronize (e->copy_stream));
+	return MTR_OK;
 }
 
 // One LV2 block: interleave into page-locked memory, one H2D copy, the kernels, one D2H copy of the stream's state

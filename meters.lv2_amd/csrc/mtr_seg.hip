@@ -547,35 +547,38 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	};
 
 	// An unaligned tile ends inside a step (the same step and frame for all lanes: every lane starts on a tile boundary).  That
-	// step's recurrence runs here, frame by frame, behind the step's products: Σ y² closes at the exact frame, the states are
-	// scrubbed there (ebu_r128_proc.cc:331-334), and the lane's last tile end is where its filter state is final — the frames of
-	// the step behind it belong to the next segment (or to k_kwtp16's tail of the call).
+	// step runs like every other one — the very code of the aligned kernel, products, split and recurrence — and then its
+	// recurrence is run AGAIN from the state the step started with, frame by frame: Σ y² closes at the exact frame, the states
+	// are scrubbed there (ebu_r128_proc.cc:331-334), and the lane's last tile end is where its filter state is final — the frames
+	// of the step behind it belong to the next segment (or to k_kwtp16's tail of the call).  One step in ~138 pays for sixteen
+	// dependent recurrence steps (+ 0.3 % of the launch); the other 137 carry no trace of the boundary (round 3 compiled a second
+	// form of the step without the recurrence and sixteen copies of the tile end into the loop: 450 registers, 1700 accumulator
+	// copies, + 1.9 % cycles on EVERY step).
 	int frames_left = (int) a.tile_frames;                            // of the open tile, at the start of the next step
 	uint32_t tiles_done = 0;
 	KState kfin = ks;
 	auto kslow = [&]<int U> () __attribute__ ((always_inline)) {
 		const v2f (&x)[R] = xq[U];
-		const int k = frames_left;                                    // 1 .. 16: frames of this step that belong to the open tile
-		auto tile_end = [&] () __attribute__ ((always_inline)) {
-			if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + a.tile0 + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
-			ks.sj = 0;
-			ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);
-			++tile;
-			if (++tiles_done == a.n_main) kfin = ks;
-		};
+		const int k = frames_left;                                    // 1 .. 16: frames of this step that belong to the open tile (wave-uniform)
 #pragma unroll
-		for (int n = 0; n < R; ++n) {
-			if (n == k) tile_end ();
-			kstep (kc, ks, x[n]);
-		}
-		if (k == R) tile_end ();
+		for (int n = 0; n < R; ++n) if (n < k) kstep (kc, ks, x[n]);
+		if (live && tile >= fq) a.tile_power[(size_t) s * a.n_tiles + a.tile0 + tile] = a.gain_l * ks.sj.x + a.gain_r * ks.sj.y;
+		ks.sj = 0;
+		ks.z1 = scrub (ks.z1); ks.z2 = scrub (ks.z2); ks.z3 = scrub (ks.z3); ks.z4 = scrub (ks.z4);
+		++tile;
+		if (++tiles_done == a.n_main) kfin = ks;
+#pragma unroll
+		for (int n = 0; n < R; ++n) if (n >= k) kstep (kc, ks, x[n]);
 		frames_left = (int) a.tile_frames - (R - k);
 	};
 	auto do_step = [&]<int U, bool PROD> () __attribute__ ((always_inline)) {
 		if constexpr (!EBU || ALIGNED) step.template operator()<U, PROD, EBU> ();
 		else {
-			if (frames_left > R) { step.template operator()<U, PROD, true> (); frames_left -= R; }
-			else { step.template operator()<U, PROD, false> (); kslow.template operator()<U> (); }
+			const bool boundary = frames_left <= R;                   // wave-uniform
+			KState at_start = ks;
+			step.template operator()<U, PROD, true> ();
+			if (boundary) { ks = at_start; kslow.template operator()<U> (); }
+			else frames_left -= R;
 		}
 	};
 

@@ -9,7 +9,8 @@
 //
 // The attack / release recurrence is a monotone piece-wise linear map of the state; compositions grow a piece per
 // value, so it is not a cheap associative scan and time stays serial per (stream, channel).  What this kernel does
-// (round 3's second form; the first interpolated on the VALU and walked 4 dependent attacks per frame and filter):
+// (round 4's form; round 3's split every 64-sample window again for every 16-frame chunk — each sample four times, in
+// the lanes of the products — which made a block of products a 1600-cycle dependent sequence):
 //
 //   * `if (v > z) z += w (v - z)` is z <- max (z, a z + w v) with a = 1 - w, and FOUR of them in a row are
 //         z <- max (z, a z + c1, a^2 z + c2, a^3 z + c3, a^4 z + c4),
@@ -18,18 +19,23 @@
 //     for any frame — and what is left ON the chain per frame and filter is one multiply, four INDEPENDENT fused
 //     multiply-adds of the same z (the release w3 folded into their slopes) and two v_max3: three dependent
 //     operations instead of nine.  Exact in real arithmetic; in f32 a few ulps from the reference's sequence (held
-//     to the 2e-6 of tests/test_gpu_parity.py::test_truepeak_ballistics_*, like the max form before it).
+//     to the 2e-6 of tests/test_gpu_parity.py::test_truepeak_ballistics_*).
 //   * the interpolator is the matrix-pipe one of mtr_mfma16_fir.h (samples and taps as two f16 halves, three partial
 //     products, f32 accumulation: within 4e-7 of the exact-f32 chain): a workgroup owns 64 (stream, channel)
-//     columns = 4 blocks of 16, a chunk is 16 frames = the rows of one block, the 64-sample window of a column
-//     sits as f32 in an LDS ring and is split in registers on its way into the MFMA, with the column's own
-//     power-of-two scale (from the window's maximum) — nothing is staged as f16.
-//   * eight waves, two per SIMD (waves w and w + 4 share one; every role is a dependent sequence and a second wave
-//     covers its latencies), balanced by instruction count: wave 0 walks the 64 chains (chunk t - 2); waves 1, 2, 3
-//     and 7 run the products of chunk t, one block of 18 MFMAs each, and leave the four values of every frame in LDS
-//     (16 bytes per frame and column: carrying w1 v, w2 v instead costs more LDS traffic than the eight multiplies it
-//     saves the map lanes — 35.5 vs 34.3 ms); waves 4, 5, 6 form the per-frame maps of chunk t - 1 (lane = column; 4, 6 and 6 frames) and wave 4
-//     fetches chunk t + 1.  Values and maps are double buffered in LDS, one barrier per chunk.
+//     columns = 4 blocks of 16, a chunk is 16 frames = the rows of one block.
+//   * EVERY SAMPLE IS SPLIT ONCE, by the wave that fetched it (lane = column), into a ring of f16 hi / lo pair words
+//     (five slots of 16 samples per column, 176 bytes per column and array: conflict-free 16-byte accesses), under a
+//     power-of-two scale per column that follows the window's maximum with hysteresis: it stands while the maximum of
+//     the 64-sample window stays in [2^7, 2^15) scaled, and when it has to move — a sample too large for it, or a window
+//     that has become 2^5 quieter than the scale was made for — the column's three older slots are rescaled in place (a
+//     power of two: exact but for what falls below f16's range, 2^-27 of the new maximum) in a cold path with its own
+//     barrier.  22 bits of every sample within 2^-11 of the window's maximum, as with a scale per window.  The products
+//     then READ their operands (four ds_read_b128 per block) instead of forming them; phase 0 (x[n - 24]) comes from the
+//     f32 ring the fetch fills, exactly.
+//   * eight waves, two per SIMD (waves w and w + 4 share one): wave 0 walks the 64 chains (chunk t - 2); waves 1 and 2 run
+//     the products of chunk t, two blocks of 18 MFMAs each, and leave the four values of every frame in LDS; wave 3
+//     fetches chunk t + 1, splits it and forms maps; waves 4 - 7 form the per-frame maps of chunk t - 1 (lane = column).
+//     Values and maps are double buffered in LDS, one barrier per chunk.
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -63,29 +69,63 @@ __device__ unsigned long long g_tpb_prof[8][4];
 
 namespace {
 
-constexpr int NW = 8;                          // wave 0: the chains; waves 1, 2, 3, 7: products; waves 4, 5, 6: per-frame maps (4: fetch)
+constexpr int NW = 8;                          // wave 0: the chains; 1, 2: products; 3: fetch + split + maps; 4 - 7: maps
 constexpr int F = 16;                          // frames per chunk = rows of one MFMA block
 constexpr int NCOL = 64;                       // (stream, channel) columns per workgroup: 32 stereo or 64 mono streams
 constexpr int RING = 5 * F;                    // samples per column: the 64-sample window of a chunk + the chunk being fetched
-constexpr int RSTRIDE = RING + 4;              // floats per column (16-byte rows; 84 = 20 mod 64: sixteen columns hit sixteen bank groups)
+constexpr int RSTRIDE = RING + 4;              // floats per column of the f32 ring (16-byte rows; 84 = 20 mod 64: sixteen columns hit sixteen bank groups)
 constexpr int RING_B = NCOL * RSTRIDE * 4;
+constexpr int HSTRIDE = 176;                   // bytes per column and array of the f16 ring: ten 16-byte pieces (8 samples as four pair words) + 16:
+                                               // 11 c mod 16 is a permutation — sixteen columns' pieces sit in sixteen bank groups
+constexpr int HRING_B = NCOL * HSTRIDE;        // one array: hi | lo
+constexpr int AUX_B = 512;                     // float un [NCOL]; int flag [2]
 constexpr int VBUF_B = F * NCOL * 16;          // a chunk of values: [frame][column] x (|x[n - 24]|, |y1|, |y2|, |y3|)
 constexpr int CBUF_B = F * 2 * NCOL * 16;      // a chunk of maps: [frame][half][column] x (c_k of filter 1, of filter 2) for k = 1, 2 | 3, 4
-constexpr int LDS_BYTES = RING_B + 2 * VBUF_B + 2 * CBUF_B;
+constexpr int LDS_BYTES = RING_B + 2 * HRING_B + AUX_B + 2 * VBUF_B + 2 * CBUF_B;
 constexpr int NTHREADS = 64 * NW;
 static_assert (RING % 8 == 0 && (RSTRIDE * 4) % 16 == 0, "operand slices never wrap inside the ring");
+static_assert (LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+
+// who forms the maps of which frames of a chunk (waves w and w + 4 share a SIMD: the chains' SIMD and the products' get
+// fewer frames than the fetch wave's)
+#ifndef MTR_TPB_MAP_SPLIT
+#define MTR_TPB_MAP_SPLIT 0, 2, 6, 10, 13, 16
+#endif
+constexpr int MAPF[6] = { MTR_TPB_MAP_SPLIT };  // wave 4: [0], [1]) ... wave 7: [3], [4]); wave 3: [4], [5])
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
 __device__ __forceinline__ v2f fma2 (v2f a, v2f b, v2f c) { return __builtin_elementwise_fma (a, b, c); }
 __device__ __forceinline__ v2f max2 (v2f a, v2f b) { return v2f{__builtin_fmaxf (a.x, b.x), __builtin_fmaxf (a.y, b.y)}; }
+
+// The scale of a column: a power of two, 2^(se - 127).  Made for a window maximum W it puts W into [2^12, 2^13); it stands
+// until a sample reaches 2^15 under it (cap: the bit pattern of that sample — non-negative floats order as uints, an Inf
+// lies above every cap that matters) or the window's maximum falls below 2^7 under it (low).
+struct ColScale {
+	int se;
+	float sc, un;                              // scale; 2^-15 / scale (the taps carry 2^15)
+	uint32_t cap, low;
+	__device__ __forceinline__ static int se_for (float w) { return min (238, 266 - (int) (__float_as_uint (w) >> 23)); }
+	__device__ __forceinline__ void set (int se_)
+	{
+		se = se_;
+		sc = __uint_as_float ((uint32_t) se << 23);
+		un = __uint_as_float ((uint32_t) (239 - se) << 23);
+		cap = (uint32_t) (269 - se) << 23;
+		low = (uint32_t) (261 - se) << 23;
+	}
+};
 
 template <int C>   // channels: 2 = interleaved stereo (column = stream + 32 channel), 1 = mono (column = stream)
 __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 {
 	constexpr int NSTR = NCOL / C;                                       // streams per workgroup
 	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-	float* const ring = reinterpret_cast<float*> (smem);                 // [NCOL][RSTRIDE]
-	unsigned char* const vbuf = smem + RING_B;                           // [2][F][NCOL] float4
+	float* const ring = reinterpret_cast<float*> (smem);                 // [NCOL][RSTRIDE] f32: exact samples
+	unsigned char* const ringh = smem + RING_B;                          // [NCOL][HSTRIDE]: f16 hi pair words, slot k at 32 k
+	unsigned char* const ringl = ringh + HRING_B;                        // ... lo
+	float* const un_sh = reinterpret_cast<float*> (ringl + HRING_B);     // [NCOL]: 2^-15 / scale of every column, as the ring holds it
+	int* const flag_sh = reinterpret_cast<int*> (un_sh + NCOL);          // [2]: a rescale is pending for the iteration of this parity
+	unsigned char* const vbuf = smem + RING_B + 2 * HRING_B + AUX_B;     // [2][F][NCOL] float4
 	unsigned char* const cbuf = vbuf + 2 * VBUF_B;                       // [2][F][2][NCOL] float4
 	const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
 	const uint32_t s0 = blockIdx.x * NSTR;
@@ -111,9 +151,9 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		for (int k = 0; k < 5; ++k) { s1[k] = (float) p1; s2[k] = (float) p2; p1 *= (double) a1; p2 *= (double) a2; }
 	}
 
-	// ---- wave 4: what it fetches ------------------------------------------------------------------------------------------
+	// ---- wave 3: what it fetches ------------------------------------------------------------------------------------------
 	// A chunk is 256 pieces of 16 bytes: stereo piece p = (stream p / 8, frames 2 (p % 8), + 1), mono piece p = (stream p / 4,
-	// frames 4 (p % 4) .. + 3).  Wave 4 fetches them, four per lane.
+	// frames 4 (p % 4) .. + 3).  Wave 3 fetches them, four per lane.
 	constexpr int NP = 4;
 	const float* prow[NP];
 	int pfr[NP], pdst[NP];
@@ -173,54 +213,116 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		}
 	};
 
-	// ---- the products (waves 1, 2, 3, 7) and the per-frame maps (waves 4, 5, 6; lane = column) -----------------------------
+	// ---- wave 3, lane = column: every sample is split ONCE into the f16 ring, under the column's scale -----------------------
+	ColScale cs;
+	cs.set (238);
+	float hm1 = 0.f, hm2 = 0.f, hm3 = 0.f;                               // max |x| of the three slots in front of the newest one
+	int pend_k = 0;                                                      // this column's older slots still carry a scale 2^-pend_k off
+	auto wave_sync = [] () {                                             // LDS written by other lanes of THIS wave is about to be read
+		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier ();
+		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
+	};
+	auto read_slot = [&] (int pos, float (&x)[F]) {                      // the column's 16 samples at ring position pos (a multiple of 16)
+		const float* const col = ring + lane * RSTRIDE + pos;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const float4 v = *reinterpret_cast<const float4*> (col + 4 * q);
+			x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+		}
+	};
+	auto slot_max = [] (const float (&x)[F]) {
+		float m = 0.f;
+#pragma unroll
+		for (int i = 0; i < F; i += 2) m = max3f (m, fabsf (x[i]), fabsf (x[i + 1]));      // (a NaN loses every maximum; an Inf is one)
+		return m;
+	};
+	auto write_slot = [&] (int pos, const float (&x)[F]) {               // ... split under cs.sc into slot pos / 16 of both arrays
+		uint32_t hw[8], lw[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) m16::split_pair (x[2 * i] * cs.sc, x[2 * i + 1] * cs.sc, hw[i], lw[i]);
+		unsigned char* const h = ringh + lane * HSTRIDE + 2 * pos;       // 16 samples = 32 bytes
+		unsigned char* const l = ringl + lane * HSTRIDE + 2 * pos;
+		*reinterpret_cast<uint4*> (h)      = uint4{hw[0], hw[1], hw[2], hw[3]};
+		*reinterpret_cast<uint4*> (h + 16) = uint4{hw[4], hw[5], hw[6], hw[7]};
+		*reinterpret_cast<uint4*> (l)      = uint4{lw[0], lw[1], lw[2], lw[3]};
+		*reinterpret_cast<uint4*> (l + 16) = uint4{lw[4], lw[5], lw[6], lw[7]};
+	};
+	// the chunk at ring position pos has landed in the f32 ring: its maximum, the scale check, the split.  If the scale has to
+	// move, the NEW chunk is written under the new scale (nobody reads its slot before the next barrier), the older slots and
+	// un_sh are left to `rescale` at the top of the next iteration — the products of this one are reading them.
+	auto split = [&] (int pos, int next_par) {
+		float x[F];
+		read_slot (pos, x);
+		const float m0 = slot_max (x);
+		const float w = max3f (max3f (m0, hm1, hm2), hm3, 0.f);
+		const int se_w = ColScale::se_for (w);
+		const bool move = __float_as_uint (m0) >= cs.cap || (__float_as_uint (w) < cs.low && se_w != cs.se);
+		if (__builtin_expect (__ballot (move) != 0, 0)) {
+			if (move) { pend_k += cs.se - se_w; cs.set (se_w); }           // (pend_k adds up if the column moved last chunk too and is not yet rescaled: it cannot be — every move is served at the next iteration's top)
+			if (lane == 0) flag_sh[next_par] = 1;
+		}
+		write_slot (pos, x);
+		hm3 = hm2; hm2 = hm1; hm1 = m0;
+	};
+	// a pending move: the three slots in front of the newest (at ring position pos) times 2^-pend_k, exactly (a power of two;
+	// what falls below f16's range is 2^-27 of the window's new maximum), and the column's un for the products
+	auto rescale = [&] (int pos) {
+		if (pend_k != 0) {
+			const int k = max (-60, min (60, -pend_k));
+			const float r = __uint_as_float ((uint32_t) (127 + k) << 23);
+			typedef _Float16 h2v __attribute__ ((ext_vector_type (2)));
+#pragma unroll 1
+			for (int back = 1; back <= 3; ++back) {
+				int p = pos - 16 * back; p += p < 0 ? RING : 0;
+#pragma unroll 1
+				for (int arr = 0; arr < 2; ++arr) {
+					unsigned char* const b = (arr ? ringl : ringh) + lane * HSTRIDE + 2 * p;
+#pragma unroll
+					for (int i = 0; i < 2; ++i) {
+						uint4 v = *reinterpret_cast<uint4*> (b + 16 * i);
+						uint32_t* const wv = reinterpret_cast<uint32_t*> (&v);
+#pragma unroll
+						for (int j = 0; j < 4; ++j) {
+							const h2v hv = __builtin_bit_cast (h2v, wv[j]);
+							wv[j] = m16::hi_pair ((float) hv.x * r, (float) hv.y * r);
+						}
+						*reinterpret_cast<uint4*> (b + 16 * i) = v;
+					}
+				}
+			}
+			un_sh[lane] = cs.un;
+			pend_k = 0;
+		}
+	};
+
+	// ---- the products (waves 1, 2: two blocks each) and the per-frame maps (lane = column) ------------------------------------
 	const int cc = lane & 15, kg = lane >> 4;
 	m16::AFrag A;
-	if ((wid >= 1 && wid <= 3) || wid == 7) A.load (a.mfma_a, lane);          // (whoever runs products)
-	// values of chunk j, block b (columns 16 b + cc; this lane: frames 4 kg .. + 3) -> vbuf
-	// NB blocks per call, stage by stage for all of them.  One block is a dependent sequence (ring read -> window maximum -> scale ->
-	// split -> 18 MFMAs -> un-scale -> store) that leaves most issue slots of its wave empty — but two blocks in one wave (NB = 2) cost
-	// more than two waves with one block each sharing a SIMD (40.3 vs 35.5 ms): NB = 1 is what runs.
+	if (wid == 1 || wid == 2) A.load (a.mfma_a, lane);
+	// values of chunk j, blocks b0, b0 + 1 (columns 16 b + cc; this lane: frames 4 kg .. + 3) -> vbuf
 	float pk[2] = { 0.f, 0.f };                                          // raw peaks of the values this lane produced (column cc of its blocks)
-	auto products = [&]<int NB> (int par, int w0, int b0, int nfl) {     // w0 = ring slot of window position 0 = frame 16 j - 48; par = j & 1;
+	auto products = [&] (int par, int w0, int b0, int nfl) {             // w0 = ring position of window position 0 = frame 16 j - 48; par = j & 1;
 	                                                                     // nfl = how many of this lane's four frames belong to the call
-		float4 x[NB][4], x0[NB];                                         // positions 32 st + 8 kg .. + 7, st = 0, 1; x[n - 24] of this lane's four frames
-#pragma unroll
-		for (int n = 0; n < NB; ++n) {
-			const float* const col = ring + (16 * (b0 + n) + cc) * RSTRIDE;
-#pragma unroll
-			for (int q = 0; q < 4; ++q) { int o = w0 + 32 * (q >> 1) + 8 * kg + 4 * (q & 1); o -= o >= RING ? RING : 0; x[n][q] = *reinterpret_cast<const float4*> (col + o); }
-			int o0 = w0 + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0;
-			x0[n] = *reinterpret_cast<const float4*> (col + o0);
-		}
-		// the column's scale: a power of two that puts the window's maximum into [2^3, 2^4) — 22 bits of every sample that matters
-		float sc[NB], un[NB];
-#pragma unroll
-		for (int n = 0; n < NB; ++n) {
-			float mx = 0.f;
-#pragma unroll
-			for (int q = 0; q < 4; ++q) mx = max3f (mx, max3f (fabsf (x[n][q].x), fabsf (x[n][q].y), fabsf (x[n][q].z)), fabsf (x[n][q].w));
-			// ... over the four lanes that hold the column's window (c, c + 16, c + 32, c + 48): two VALU lane swaps, not two trips through the LDS crossbar
-			typedef unsigned u2 __attribute__ ((ext_vector_type (2)));
-			const u2 r16 = __builtin_amdgcn_permlane16_swap (__float_as_uint (mx), __float_as_uint (mx), false, false);
-			mx = __builtin_fmaxf (__uint_as_float (r16.x), __uint_as_float (r16.y));
-			const u2 r32 = __builtin_amdgcn_permlane32_swap (__float_as_uint (mx), __float_as_uint (mx), false, false);
-			mx = __builtin_fmaxf (__uint_as_float (r32.x), __uint_as_float (r32.y));
-			const int e = (int) (__float_as_uint (mx) >> 23);
-			const int se = min (238, 257 - e);
-			sc[n] = __uint_as_float ((uint32_t) se << 23); un[n] = __uint_as_float ((uint32_t) (239 - se) << 23);
-		}
+		constexpr int NB = 2;
 		m16::BFrag B[NB];
+		float4 x0[NB];                                                   // x[n - 24] of this lane's four frames, exact
+		float un[NB];
+		// window positions 32 st + 8 kg .. + 7 = the 16-byte piece (w0 / 8 + 4 st + kg) mod 10 of the column
+		int q0 = (w0 >> 3) + kg; q0 -= q0 >= 10 ? 10 : 0;
+		int q1 = q0 + 4; q1 -= q1 >= 10 ? 10 : 0;
 #pragma unroll
 		for (int n = 0; n < NB; ++n) {
-			uint32_t hw[8], lw[8];
-#pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				m16::split_pair (x[n][q].x * sc[n], x[n][q].y * sc[n], hw[2 * q], lw[2 * q]);
-				m16::split_pair (x[n][q].z * sc[n], x[n][q].w * sc[n], hw[2 * q + 1], lw[2 * q + 1]);
-			}
-			B[n].h0 = uint4{hw[0], hw[1], hw[2], hw[3]}; B[n].h1 = uint4{hw[4], hw[5], hw[6], hw[7]};
-			B[n].l0 = uint4{lw[0], lw[1], lw[2], lw[3]}; B[n].l1 = uint4{lw[4], lw[5], lw[6], lw[7]};
+			const int col = 16 * (b0 + n) + cc;
+			const unsigned char* const h = ringh + col * HSTRIDE;
+			const unsigned char* const l = ringl + col * HSTRIDE;
+			B[n].h0 = *reinterpret_cast<const uint4*> (h + 16 * q0);
+			B[n].h1 = *reinterpret_cast<const uint4*> (h + 16 * q1);
+			B[n].l0 = *reinterpret_cast<const uint4*> (l + 16 * q0);
+			B[n].l1 = *reinterpret_cast<const uint4*> (l + 16 * q1);
+			int o0 = w0 + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0;
+			x0[n] = *reinterpret_cast<const float4*> (ring + col * RSTRIDE + o0);
+			un[n] = un_sh[col];
 		}
 		m16::f4 y[NB][3];
 #pragma unroll
@@ -269,18 +371,31 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// ---- prologue: the 48 frames before the call (47 of history; frame -48 is never multiplied by a non-zero tap) and chunk 0 ----
 	if (wid != 0) {
 		for (int e = (wid - 1) * 64 + lane; e < NCOL * 48; e += (NW - 1) * 64) {
-			const int col = e / 48, i = e % 48;                              // frame i - 48 -> ring slot 32 + i
+			const int col = e / 48, i = e % 48;                              // frame i - 48 -> ring position 32 + i
 			const uint32_t s = s0 + (uint32_t) (C == 2 ? (col & 31) : col);
 			float x = 0.f;
 			if (s < a.n_streams && i >= 1)                                   // history rows are [frame][2], right channel zero for mono engines
 				x = a.hist[((size_t) s * MTR_FIR_HALO + (size_t) (i - 1)) * 2 + (C == 2 ? (col >> 5) : 0)];
 			ring[col * RSTRIDE + 32 + i] = x;
 		}
-		if (wid == 4) { fetch (0); put (0); }
+		if (wid == 3) { fetch (0); put (0); }
+	}
+	if (threadIdx.x < 2) flag_sh[threadIdx.x] = 0;
+	__syncthreads ();
+	if (wid == 3) {
+		// the first window: one scale for its four slots, from their common maximum
+		float x[4][F];
+		read_slot (32, x[0]); read_slot (48, x[1]); read_slot (64, x[2]); read_slot (0, x[3]);
+		hm3 = slot_max (x[0]); hm2 = slot_max (x[1]); hm1 = slot_max (x[2]);
+		const float m0 = slot_max (x[3]);
+		cs.set (ColScale::se_for (max3f (max3f (m0, hm1, hm2), hm3, 0.f)));
+		write_slot (32, x[0]); write_slot (48, x[1]); write_slot (64, x[2]); write_slot (0, x[3]);
+		un_sh[lane] = cs.un;
+		hm3 = hm2; hm2 = hm1; hm1 = m0;
 	}
 	__syncthreads ();
 
-	// iteration t: chunk t + 1 is fetched, chunk t goes through the products, chunk t - 1 through the maps, chunk t - 2 through the chains
+	// iteration t: chunk t + 1 is fetched and split, chunk t goes through the products, chunk t - 1 through the maps, chunk t - 2 through the chains
 #ifdef MTR_TPB_PROF
 	unsigned long long pr[4] = { 0, 0, 0, 0 };
 #endif
@@ -310,28 +425,43 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	int slot_w = 32, slot_p = F % RING;                                  // window start of chunk t; where chunk t + 1 goes
 	constexpr int LAG = 2;                                               // chunks between the products and the chains
 	for (int64_t t = 0; t < n_chunks + LAG; ++t) {
-		PROF_NOW (c0_);
 		const int par = (int) (t & 1);
+		// a column's scale moved when chunk t was split (last iteration): its older slots and its un follow now, before this
+		// iteration's products read them — the cold path, with its own barrier (the flag is uniform: every wave reads it here,
+		// and wave 3 clears it only behind that barrier)
+		const int moved = __builtin_amdgcn_readfirstlane (flag_sh[par]);
+		if (__builtin_expect (moved != 0, 0)) {
+			if (wid == 3) rescale (slot_w + 48 >= RING ? slot_w + 48 - RING : slot_w + 48);       // chunk t's own slot = the window's last
+			__syncthreads ();
+			if (wid == 3 && lane == 0) flag_sh[par] = 0;
+		}
+		PROF_NOW (c0_);
 		if (wid == 0) {
 			if (t >= LAG && !MTR_TPB_DBG_NOCHAIN) {
 				const int64_t left = n_frames - (t - LAG) * F;
 				if (left >= F) chain.template operator()<true> (par ^ (LAG & 1), F);
 				else chain.template operator()<false> (par ^ (LAG & 1), (int) left);
 			}
-		} else if (wid <= 3 || wid == 7) {
+		} else if (wid <= 2) {
 			if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
 				const int64_t left = n_frames - t * F - 4 * kg;                 // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
-				products.template operator()<1> (par, slot_w, wid == 7 ? 3 : wid - 1, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
+				products (par, slot_w, 2 * (wid - 1), left >= 4 ? 4 : (left > 0 ? (int) left : 0));
 			}
 		} else {
 			const bool more = t + 1 < n_chunks;
-			if (wid == 4 && more && !MTR_TPB_DBG_NOFETCH) fetch (t + 1);
+			if (wid == 3 && more && !MTR_TPB_DBG_NOFETCH) fetch (t + 1);
 			if (t >= 1 && t - 1 < n_chunks && !MTR_TPB_DBG_NOMAPS) {
-				if (wid == 4) maps.template operator()<0, 4> (par ^ 1);
-				else if (wid == 5) maps.template operator()<4, 10> (par ^ 1);
-				else maps.template operator()<10, 16> (par ^ 1);
+				if (wid == 4) maps.template operator()<MAPF[0], MAPF[1]> (par ^ 1);
+				else if (wid == 5) maps.template operator()<MAPF[1], MAPF[2]> (par ^ 1);
+				else if (wid == 6) maps.template operator()<MAPF[2], MAPF[3]> (par ^ 1);
+				else if (wid == 7) maps.template operator()<MAPF[3], MAPF[4]> (par ^ 1);
+				else maps.template operator()<MAPF[4], MAPF[5]> (par ^ 1);
 			}
-			if (wid == 4 && more && !MTR_TPB_DBG_NOFETCH) put (slot_p);
+			if (wid == 3 && more && !MTR_TPB_DBG_NOFETCH) {
+				put (slot_p);
+				wave_sync ();
+				split (slot_p, par ^ 1);
+			}
 		}
 		PROF_NOW (c1_);
 		__syncthreads ();
@@ -349,8 +479,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	uint32_t* const pk_sh = reinterpret_cast<uint32_t*> (ring);          // the ring is spent
 	if (wid == 0) pk_sh[lane] = 0u;
 	__syncthreads ();
-	if (wid <= 3 && wid >= 1) atomicMax (&pk_sh[16 * (wid - 1) + cc], __float_as_uint (pk[0]));
-	if (wid == 7) atomicMax (&pk_sh[48 + cc], __float_as_uint (pk[0]));
+	if (wid == 1 || wid == 2) {
+		atomicMax (&pk_sh[32 * (wid - 1) + cc], __float_as_uint (pk[0]));
+		atomicMax (&pk_sh[32 * (wid - 1) + 16 + cc], __float_as_uint (pk[1]));
+	}
 	__syncthreads ();
 	if (wid == 0 && owner) {
 		st->tpb_z1[ch] = z1 + 1e-20f;                                    // truepeakdsp.cc:86-87

@@ -97,6 +97,7 @@ def _load():
     L.mtr_engine_spectr_set_speed.argtypes = [vp, f32]
     L.mtr_engine_process_device.argtypes = [vp, vp, u64, u64, vp]
     L.mtr_engine_process_host.argtypes = [vp, vp, u64, u64]
+    L.mtr_engine_set_host_chunk_bytes.argtypes = [vp, u64]
     L.mtr_engine_process_planar_host.argtypes = [vp, C.POINTER(vp), u32]
     L.mtr_engine_results.argtypes = [vp, u32, u32, C.POINTER(StreamResult)]
     L.mtr_engine_histograms.argtypes = [vp, u32, u32, vp, vp]
@@ -273,6 +274,10 @@ class Engine:
         x = np.ascontiguousarray(x, np.float32)
         assert x.shape[0] == self.n_streams
         _check(lib.mtr_engine_process_host(self._h, x.ctypes.data, x.shape[1], x.shape[1]), "process_host")
+
+    def set_host_chunk_bytes(self, n):
+        """Bytes of audio per chunk of process() (host memory crosses the link chunk by chunk under the kernels)."""
+        _check(lib.mtr_engine_set_host_chunk_bytes(self._h, n), "set_host_chunk_bytes")
 
     def process_planar(self, chans):
         arrs = [np.ascontiguousarray(c, np.float32) for c in chans]

@@ -453,6 +453,64 @@ def test_truepeak_ballistics_batch(M, oracle):
                 assert abs(got[i][s][c][1] - p.value) < 2e-6 * max(1.0, p.value), (s, c, i)
 
 
+def test_truepeak_ballistics_column_scale_moves(M, oracle):
+    """k_tpb splits every sample once, into a ring of f16 halves under a power-of-two scale per column that follows the
+    window's maximum with hysteresis and rescales the ring in place when it has to move (mtr_tpb.hip).  Signals that make
+    it move: 120 dB down and up again, digital silence in between, a ramp of 6 dB per millisecond over 240 dB, lone
+    full-scale samples in quiet noise (the scale shrinks for 64 frames and grows back, every time), an Inf and a NaN.
+    Level and peak per call against TruePeakdsp::process / read — RELATIVE to the value itself here (4e-6; the other tests
+    allow 2e-6 of max (1, value), which says nothing about a call that lies in a quiet stretch)."""
+    import ctypes as C
+    from _oracle import MoTp
+    fs, T = 48000.0, 75000
+    n = [sig.lcg_noise(T, 900 + s, 1.0) for s in range(5)]
+    a = n[0] * np.float32(0.5)
+    a[20000:50000] *= np.float32(2.0 ** -20); a[50000:55000] = 0.0; a[55000:65000] *= np.float32(2.0 ** -10); a[65000:] *= np.float32(1.8)
+    b = n[1].copy()
+    up = np.minimum(np.arange(T) - 3000, 48 * 40) / 48.0
+    b *= (np.float32(2.0) ** (up - 40.0))[:, None].astype(np.float32)
+    b[:3000] = 0.0
+    b[40000:] *= (np.float32(2.0) ** (-(np.arange(T - 40000) / 96.0)))[:, None].astype(np.float32)        # ... and down again, 3 dB per ms, into denormals
+    c = n[2] * np.float32(2.0 ** -8)
+    c[777::777, 0] = 1.0; c[1000::1554, 1] = -0.75
+    d = n[3] * np.float32(0.25); d[30000, 0] = np.inf; d[30000, 1] = np.nan
+    e_ = n[4] * np.float32(1e-12); e_[60000:] *= np.float32(1e8)       # (far above the 1e-20f the reference adds to its states per block)
+    x = np.stack([a, b, c, d, e_])
+    cuts = (0, 7000, 7033, 26000, 52000, 52001, 66000, T)
+    with M.Engine(5, fs, M.METER_TPBALLIST) as eng:
+        got = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            eng.process(np.ascontiguousarray(x[:, lo:hi]))
+            r = eng.results()
+            got.append([[(r[s].tpb_level[ch], r[s].tpb_peak[ch]) for ch in range(2)] for s in range(5)])
+    for s in range(5):
+        for ch in range(2):
+            col = np.ascontiguousarray(x[s, :, ch])
+            t = MoTp()
+            oracle.lib.mo_tp_init(C.byref(t), fs)
+            m, p = C.c_float(), C.c_float()
+            for i, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+                mm = pp = 0.0
+                for o in range(lo, hi, 8192):
+                    seg = np.ascontiguousarray(col[o:min(o + 8192, hi)])
+                    oracle.lib.mo_tp_process(C.byref(t), seg, seg.size)
+                    oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
+                    mm, pp = max(mm, m.value), max(pp, p.value)
+                gm, gp = got[i][s][ch]
+                if s == 3 and i >= 3:
+                    # From the call with the Inf / NaN sample on.  The Inf is that call's peak and level, as in the reference (which
+                    # would clamp the state at the next 8192-frame block; one engine call is one block, so the levels behind it are
+                    # not comparable).  The NaN's channel comes back finite: a NaN loses every `v > z` and every maximum.
+                    if ch == 0 and i == 3:
+                        assert gp == np.inf and gm == np.inf and mm == np.inf, (gm, gp, mm, pp)
+                    assert not np.isnan(gm) and not np.isnan(gp), (ch, i, gm, gp)
+                    if ch == 1:
+                        assert np.isfinite(gm) and np.isfinite(gp), (i, gm, gp)
+                    continue
+                assert abs(gm - mm) <= 4e-6 * mm + 1e-37, (s, ch, i, gm, mm)
+                assert abs(gp - pp) <= 4e-6 * pp + 1e-37, (s, ch, i, gp, pp)
+
+
 def test_truepeak_ballistics_full_size_properties(M, oracle):
     """TruePeakdsp::process at the per-GPU shard of the bench (8192 streams x 10 s) through size-independent properties:
     determinism; exact x2 scaling (a power-of-two gain is exact in fp32, in the f16 split — the column's scale moves with

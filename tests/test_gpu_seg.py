@@ -207,18 +207,35 @@ def test_seg_warm_up_bound_after_level_drops(M, oracle):
     assert got["seg"] == (1, T)
     one = _run(M, x, [T], tune_segments=1, tune_layout=7)              # the same kernel with the state carried all the way
     first = np.arange(1, segs) * (seglen // 2400)
-    rest = np.setdiff1d(np.arange(T // 2400), first)
+    # Under the DC offset itself the reference's own f32 recurrence has little to say about the programme below it: the second
+    # integrator sits at ~4e4 x 0.5, one ulp of it is 1e-3 — 20 dB above the -80 dBFS noise's K-weighted output, and all there
+    # is at -100 / -120 dBFS (tests/test_gpu_parity.py::test_dc_offset_under_quiet_programme: 1e-3 at -60 dBFS).  Those fragments
+    # are held to 5e-3 at -80 dBFS and left alone below; they sit far under the -70 LUFS gate and never reach I.  What this test
+    # is about — the quiet stretch around every segment boundary, and every fragment a switch falls into — is well conditioned.
+    dc_on = np.zeros(T, bool)
+    for q_ in range(segs):
+        dc_on[q_ * seglen + (9600 if q_ else 0):(q_ + 1) * seglen - 3840] = True
+    all_on = dc_on.reshape(-1, 2400).all(1)
     for s, (kind, q) in enumerate(cases):
         ref = oracle.ebu(x[s], 48000.0, 2400, want_frag=True)
         dev = np.abs(got["frag"][s].astype(np.float64) / ref["frag_power"] - 1)
+        dev1 = np.abs(one["frag"][s].astype(np.float64) / ref["frag_power"] - 1)
+        sound = np.ones(T // 2400, bool) if kind == "tone" else ~all_on
+        rest = np.setdiff1d(np.flatnonzero(sound), first)
         assert dev[first].max() <= WARM_BOUND[q], (kind, q, dev[first])
         assert dev[rest].max() <= 2e-5, (kind, q, dev[rest].max(), rest[dev[rest].argmax()])
-        assert np.abs(one["frag"][s].astype(np.float64) / ref["frag_power"] - 1).max() <= 2e-5, (kind, q)
-        assert np.allclose(got["o9"][s, :4], ref["out9"][:4], atol=1e-3), (kind, q, got["o9"][s], ref["out9"])
+        assert dev1[sound].max() <= 2e-5, (kind, q, dev1[sound].max())
+        if kind == "dc" and q == -80:
+            assert dev[all_on].max() <= 5e-3 and dev1[all_on].max() <= 5e-3, (dev[all_on].max(), dev1[all_on].max())
+        # in dB: what the worst well-conditioned fragment is off by
+        assert 10 * np.log10(1 + dev[sound].max()) <= 0.005
+        # M / S / I: maxima and the integrated value everywhere (they come from the loud stretches and the switches); the
+        # momentary / short-term values at the END of the stream are rounding noise of the reference under the DC at -100 / -120
+        tight = kind == "tone" or q == -80
+        for i in ((0, 1, 2, 3) if tight else (1, 3)):
+            assert abs(got["o9"][s, i] - ref["out9"][i]) <= (1e-3 if kind == "tone" else 0.01), (kind, q, i, got["o9"][s], ref["out9"])
         assert abs(got["o9"][s, 4] - ref["out9"][4]) <= 0.01 and abs(got["o9"][s, 5] - ref["out9"][5]) <= 0.01, (kind, q)
         assert np.abs(got["hist"][0][s] - ref["hist_M"]).sum() // 2 <= 2 and np.abs(got["hist"][1][s] - ref["hist_S"]).sum() // 2 <= 2
-        # in dB: what the worst fragment is off by
-        assert 10 * np.log10(1 + dev.max()) <= 0.005
 
 
 def test_seg_warm_up_under_a_dc_offset(M, oracle):

@@ -27,6 +27,12 @@ for seed in range(first, first + count):
     if seed % 5 == 0:
         x[:, T // 2:] *= np.float32(2.0 ** 6)                        # a level jump: the column scales move (levels stay under the clamp at
                                                                      # 20, which the oracle's 8192-frame blocks would apply inside a call)
+    if seed % 7 == 0:
+        x[:, :T // 3] = 0.0                                            # digital silence first: the column scales start at their ceiling
+    if seed % 11 == 0:
+        x[:, 2 * T // 3:] *= np.float32(2.0 ** -18)                   # a drop the hysteresis has to follow (the scale grows back)
+    if seed % 13 == 0 and T > 100:
+        x[:, T // 4::max(T // 9, 70), 0] = np.float32(0.9)            # lone loud samples: shrink for 64 frames, grow again
     if chn == 1:
         x = np.ascontiguousarray(x[:, :, :1])
     try:

@@ -43,7 +43,7 @@ int main (int argc, char** argv)
 	hipMemcpyFromSymbol (pr, HIP_SYMBOL (g_tpb_prof), sizeof pr);
 	const double nchunk = (double) ((T + F - 1) / F + 2);
 	printf ("S=%u T=%llu: %.3f ms, %.0f ns per chunk of %d frames\n", S, (unsigned long long) T, ms, ms * 1e6 / nchunk, F);
-	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (wave 0: the chains; 1, 2, 3, 7: one block of products each; 4, 5, 6: maps of 4, 6, 6 frames; 4 fetches)\n");
+	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (wave 0: the chains; 1, 2: two blocks of products each; 3: fetch + split + maps; 4 - 7: maps — MTR_TPB_MAP_SPLIT)\n");
 	for (int w = 0; w < NW; ++w) printf ("  %2d  %7.1f  %7.1f  %7.1f\n", w, pr[w][0] / nchunk, pr[w][2] / nchunk, pr[w][3] / nchunk);
 	return 0;
 }
