@@ -1042,8 +1042,9 @@ int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_fra
 	HIPCHK (hipSetDevice (e->cfg.device));
 	const size_t C = e->cfg.n_channels;
 	const uint32_t S = e->cfg.n_streams;
-	// (streams start on 16 bytes in the staging buffers: an even stride, so that every layout can take the call)
-	const uint64_t dstride = (n_frames + 1) & ~(uint64_t) 1;
+	// (streams start on 16 bytes in the staging buffers — an even stride of stereo frames, a multiple of four mono ones — so that
+	// every layout can take the call and k_tpb's LDS-DMA its source)
+	const uint64_t dstride = C == 1 ? (n_frames + 3) & ~(uint64_t) 3 : (n_frames + 1) & ~(uint64_t) 1;
 	const size_t row = (size_t) dstride * C;                                  // floats per staged stream
 	uint32_t cs = (uint32_t) std::min<uint64_t> (S, std::max<uint64_t> (1, e->host_chunk_bytes / (row * sizeof (float))));
 	const uint32_t n_chunks = (S + cs - 1) / cs;

@@ -66,6 +66,23 @@ __device__ unsigned long long g_tpb_prof[8][4];
 #ifndef MTR_TPB_DBG_NOFETCH
 #define MTR_TPB_DBG_NOFETCH 0
 #endif
+#ifndef MTR_TPB_DBG_NOSPLIT
+#define MTR_TPB_DBG_NOSPLIT 0
+#endif
+#ifndef MTR_TPB_DBG_NOPUT
+#define MTR_TPB_DBG_NOPUT 0
+#endif
+#ifndef MTR_TPB_DBG_NODMA
+#define MTR_TPB_DBG_NODMA 0
+#endif
+// MTR_TPB_FUSED = 1: the lanes that produce a frame's four values form its maps too (pair maps: ten instructions per frame)
+// and write them where the chains read them — no values in LDS, no map waves, one chunk less between products and chains
+#ifndef MTR_TPB_FUSED
+#define MTR_TPB_FUSED 1
+#endif
+#ifndef MTR_TPB_PAIRMAPS
+#define MTR_TPB_PAIRMAPS 1
+#endif
 
 namespace {
 
@@ -81,17 +98,29 @@ constexpr int HRING_B = NCOL * HSTRIDE;        // one array: hi | lo
 constexpr int AUX_B = 512;                     // float un [NCOL]; int flag [2]
 constexpr int VBUF_B = F * NCOL * 16;          // a chunk of values: [frame][column] x (|x[n - 24]|, |y1|, |y2|, |y3|)
 constexpr int CBUF_B = F * 2 * NCOL * 16;      // a chunk of maps: [frame][half][column] x (c_k of filter 1, of filter 2) for k = 1, 2 | 3, 4
-constexpr int LDS_BYTES = RING_B + 2 * HRING_B + AUX_B + 2 * VBUF_B + 2 * CBUF_B;
+constexpr int STG_B = 3 * 4 * 64 * 16;         // three chunks in flight from HBM, as the LDS-DMA leaves them: [chunk][piece 64 i + lane] x 16 bytes
+constexpr int LDS_BYTES = RING_B + 2 * HRING_B + AUX_B + 2 * VBUF_B + 2 * CBUF_B + STG_B;
 constexpr int NTHREADS = 64 * NW;
 static_assert (RING % 8 == 0 && (RSTRIDE * 4) % 16 == 0, "operand slices never wrap inside the ring");
 static_assert (LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 // who forms the maps of which frames of a chunk (waves w and w + 4 share a SIMD: the chains' SIMD and the products' get
 // fewer frames than the fetch wave's)
-#ifndef MTR_TPB_MAP_SPLIT
-#define MTR_TPB_MAP_SPLIT 0, 2, 6, 10, 13, 16
+// MTR_TPB_PROD_WAVES = 2: waves 1, 2 run two blocks of products each; waves 4, 5, 6, 7, 3 the maps of MAPF[0..1), [1..2), ... [4..5)
+//                    = 4: waves 1, 2, 5, 6 run one block each (two products waves per SIMD cover each other's latencies);
+//                         waves 4, 7, 3 the maps of MAPF[0..1), [1..2), [2..3)
+#ifndef MTR_TPB_PROD_WAVES
+#define MTR_TPB_PROD_WAVES 4
 #endif
-constexpr int MAPF[6] = { MTR_TPB_MAP_SPLIT };  // wave 4: [0], [1]) ... wave 7: [3], [4]); wave 3: [4], [5])
+#ifndef MTR_TPB_MAP_SPLIT
+#if MTR_TPB_PROD_WAVES == 2
+#define MTR_TPB_MAP_SPLIT 0, 2, 6, 10, 13, 16
+#else
+#define MTR_TPB_MAP_SPLIT 0, 3, 10, 16, 16, 16
+#endif
+#endif
+constexpr int MAPF[6] = { MTR_TPB_MAP_SPLIT };
+constexpr int PW = MTR_TPB_PROD_WAVES;
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
 __device__ __forceinline__ v2f fma2 (v2f a, v2f b, v2f c) { return __builtin_elementwise_fma (a, b, c); }
@@ -167,49 +196,57 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		prow[i] = a.audio + (size_t) (plive[i] ? s0 + (uint32_t) row : s0) * a.stride * C;
 		pdst[i] = row * RSTRIDE + pfr[i];                                // (stereo: the right channel's column is 32 further)
 	}
-	float4 pv[NP];
-	// prow[i] points at the piece's first frame of chunk 0; a chunk further is F frames further.  Whole chunks take the
-	// path without bounds arithmetic (a row of a stream past the batch re-reads stream s0 and is zeroed when it is stored).
-	const float* pcur[NP];
+	// A WHOLE chunk travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no register holds data in flight, so nothing
+	// makes the wave wait for it but the one s_waitcnt below), THREE iterations ahead of its products: HBM's latency is
+	// ~2500 cycles under this kernel's access pattern — one 128-byte line per stream and chunk, 1 MB in flight chip-wide per
+	// chunk of prefetch distance — more than a whole chunk's time.  (Rounds 2 and 3 loaded a chunk into registers and used
+	// it in the same iteration; round 4's first forms kept it in registers across the barrier, one and two chunks ahead: the
+	// compiler's wait counts at a loop's back edge are conservative, vmcnt (0), and every form waited for the youngest
+	// loads.  That wait was what bound this kernel: tools/tpb_prof.hip, MTR_TPB_DBG_NOFETCH.)  The lane-linear destination
+	// is the [piece] order the lanes read back.  The call's ragged last chunk, and every chunk of a batch whose streams do
+	// not start on 16 bytes, is loaded and stored in one go.
+	unsigned char* const stg = cbuf + 2 * CBUF_B;
+	const bool dma_ok = (reinterpret_cast<size_t> (a.audio) & 15) == 0 && (a.n_streams == 1 || ((a.stride * C) & 3) == 0);
+	// What lane l of DMA instruction i brings: stereo — frames 4 i + 2 (l >> 5), + 1 of stream l & 31 (both channels); mono —
+	// frames 4 i .. + 3 of stream l.  The sixteen lanes that later read a piece index k of sixteen neighbouring streams find
+	// them 16 bytes apart: conflict-free.  (A stream past the batch re-reads stream s0; its column is zeroed when it is split.)
+	const float* dsrc[NP];
+	{
+		const uint32_t row = C == 2 ? (uint32_t) (lane & 31) : (uint32_t) lane;
+		const float* const base = a.audio + (size_t) (s0 + row < a.n_streams ? s0 + row : s0) * a.stride * C;
 #pragma unroll
-	for (int i = 0; i < NP; ++i) pcur[i] = prow[i] + (size_t) pfr[i] * C;
-	auto fetch = [&] (int64_t j) {
-		if ((j + 1) * F <= n_frames) {
-#pragma unroll
-			for (int i = 0; i < NP; ++i) {
-				const float* const q = pcur[i] + (size_t) j * (F * C);
-				if (C == 2) {
-					const v2f u = *reinterpret_cast<const v2f*> (q), v = *reinterpret_cast<const v2f*> (q + 2);
-					pv[i] = float4{u.x, u.y, v.x, v.y};
-				} else pv[i] = float4{q[0], q[1], q[2], q[3]};
-				if (!plive[i]) pv[i] = float4{0.f, 0.f, 0.f, 0.f};
-			}
-			return;
-		}
+		for (int i = 0; i < NP; ++i) dsrc[i] = base + (C == 2 ? (4 * i + 2 * (lane >> 5)) * 2 : 4 * i);
+	}
+	const uint32_t stg_lds = (uint32_t) (size_t) (__attribute__ ((address_space (3))) unsigned char*) stg;
+	// (as inline assembly: the compiler must not know that these write LDS — it would wait for them, vmcnt (0), in front of
+	// every LDS access and every barrier that follows, and the point is that they stay in flight across three barriers)
+	auto dma = [&] (int64_t j, int buf) __attribute__ ((always_inline)) {   // whole chunks only: (j + 1) F <= n_frames
 #pragma unroll
 		for (int i = 0; i < NP; ++i) {
-			const int64_t f = j * F + pfr[i];
-			if (C == 2) {
-				const v2f* const q = reinterpret_cast<const v2f*> (prow[i]);
-				const v2f u = q[f < n_frames ? f : 0], v = q[f + 1 < n_frames ? f + 1 : 0];
-				pv[i] = float4{plive[i] && f < n_frames ? u.x : 0.f, plive[i] && f < n_frames ? u.y : 0.f,
-				               plive[i] && f + 1 < n_frames ? v.x : 0.f, plive[i] && f + 1 < n_frames ? v.y : 0.f};
-			} else {
-				float x[4];
-#pragma unroll
-				for (int k = 0; k < 4; ++k) { const float v = prow[i][f + k < n_frames ? f + k : 0]; x[k] = plive[i] && f + k < n_frames ? v : 0.f; }
-				pv[i] = float4{x[0], x[1], x[2], x[3]};
-			}
+			const float* const g = dsrc[i] + (size_t) j * (F * C);
+			const uint32_t l = stg_lds + (uint32_t) (buf * NP + i) * 1024u;
+			asm volatile ("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(l) : "memory");       // (m0 is reserved: the compiler writes it right in front of whatever needs it and keeps nothing there)
 		}
 	};
-	auto put = [&] (int slot) {                                          // slot = ring position of the chunk's first frame
-#pragma unroll
+	auto store = [&] (int i, int slot, float4 v) __attribute__ ((always_inline)) {
+		float* const d = ring + pdst[i] + slot;
+		if (!plive[i]) v = float4{0.f, 0.f, 0.f, 0.f};                   // a row of a stream past the batch (it re-read stream s0)
+		if (C == 2) {                                                    // v = L0 R0 L1 R1
+			*reinterpret_cast<v2f*> (d) = v2f{v.x, v.z};
+			*reinterpret_cast<v2f*> (d + 32 * RSTRIDE) = v2f{v.y, v.w};
+		} else *reinterpret_cast<float4*> (d) = v;
+	};
+	auto fetch_put_ragged = [&] (int64_t j, int slot) __attribute__ ((always_inline)) {   // any chunk, zeros behind the call's last frame
+#pragma unroll 1
 		for (int i = 0; i < NP; ++i) {
-			float* const d = ring + pdst[i] + slot;
-			if (C == 2) {
-				*reinterpret_cast<v2f*> (d) = v2f{pv[i].x, pv[i].z};
-				*reinterpret_cast<v2f*> (d + 32 * RSTRIDE) = v2f{pv[i].y, pv[i].w};
-			} else *reinterpret_cast<float4*> (d) = pv[i];
+			const int64_t f = j * F + pfr[i];
+			float x[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int64_t fk = C == 2 ? f + (k >> 1) : f + k;
+				x[k] = fk < n_frames ? prow[i][(size_t) fk * C + (C == 2 ? (k & 1) : 0)] : 0.f;
+			}
+			store (i, slot, float4{x[0], x[1], x[2], x[3]});
 		}
 	};
 
@@ -251,19 +288,50 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// the chunk at ring position pos has landed in the f32 ring: its maximum, the scale check, the split.  If the scale has to
 	// move, the NEW chunk is written under the new scale (nobody reads its slot before the next barrier), the older slots and
 	// un_sh are left to `rescale` at the top of the next iteration — the products of this one are reading them.
-	auto split = [&] (int pos, int next_par) {
-		float x[F];
-		read_slot (pos, x);
+	auto split_regs = [&] (const float (&x)[F], int pos, int next_par) __attribute__ ((always_inline)) {
 		const float m0 = slot_max (x);
 		const float w = max3f (max3f (m0, hm1, hm2), hm3, 0.f);
 		const int se_w = ColScale::se_for (w);
 		const bool move = __float_as_uint (m0) >= cs.cap || (__float_as_uint (w) < cs.low && se_w != cs.se);
 		if (__builtin_expect (__ballot (move) != 0, 0)) {
-			if (move) { pend_k += cs.se - se_w; cs.set (se_w); }           // (pend_k adds up if the column moved last chunk too and is not yet rescaled: it cannot be — every move is served at the next iteration's top)
+			if (move) { pend_k += cs.se - se_w; cs.set (se_w); }           // (every move is served at the next iteration's top: pend_k never adds up)
 			if (lane == 0) flag_sh[next_par] = 1;
 		}
 		write_slot (pos, x);
 		hm3 = hm2; hm2 = hm1; hm1 = m0;
+	};
+	auto split = [&] (int pos, int next_par) __attribute__ ((always_inline)) {      // from the f32 ring (the chunk was stored there piece by piece)
+		float x[F];
+		read_slot (pos, x);
+		split_regs (x, pos, next_par);
+	};
+	// from the staging area the LDS-DMA filled: this column's sixteen samples go to the f32 ring (exact: phase 0) and,
+	// split, to the f16 ring — one trip through the LDS each way
+	auto split_staged = [&] (int buf, int pos, int next_par) __attribute__ ((always_inline)) {
+		float x[F];
+		const unsigned char* const b = stg + buf * (NP * 1024);
+		if (C == 2) {
+			const int r = lane & 31;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const float4 v = *reinterpret_cast<const float4*> (b + (k >> 1) * 1024 + (r + 32 * (k & 1)) * 16);
+				x[2 * k] = ch ? v.y : v.x; x[2 * k + 1] = ch ? v.w : v.z;
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const float4 v = *reinterpret_cast<const float4*> (b + i * 1024 + lane * 16);
+				x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+			}
+		}
+		if (!owner) {
+#pragma unroll
+			for (int i = 0; i < F; ++i) x[i] = 0.f;
+		}
+		float* const col = ring + lane * RSTRIDE + pos;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*> (col + 4 * q) = float4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+		split_regs (x, pos, next_par);
 	};
 	// a pending move: the three slots in front of the newest (at ring position pos) times 2^-pend_k, exactly (a power of two;
 	// what falls below f16's range is 2^-27 of the window's new maximum), and the column's un for the products
@@ -296,15 +364,22 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		}
 	};
 
+	const v2f AA = v2f{a1, a2};
 	// ---- the products (waves 1, 2: two blocks each) and the per-frame maps (lane = column) ------------------------------------
 	const int cc = lane & 15, kg = lane >> 4;
 	m16::AFrag A;
-	if (wid == 1 || wid == 2) A.load (a.mfma_a, lane);
+	const bool prod_wave = wid == 1 || wid == 2 || (PW == 4 && (wid == 5 || wid == 6));
+	if (prod_wave) {
+		A.load (a.mfma_a, lane);
+		// (used — waited for — right here: a load still pending where the roles part makes the compiler guard every register it
+		// might land in with a vmcnt wait, in EVERY role's loop, and in wave 3's that wait would be for the LDS-DMA in flight)
+#pragma unroll
+		for (int f = 0; f < MTR_M16_FRAGS; ++f) asm volatile ("" : "+v"(A.a[f]));
+	}
 	// values of chunk j, blocks b0, b0 + 1 (columns 16 b + cc; this lane: frames 4 kg .. + 3) -> vbuf
 	float pk[2] = { 0.f, 0.f };                                          // raw peaks of the values this lane produced (column cc of its blocks)
-	auto products = [&] (int par, int w0, int b0, int nfl) {             // w0 = ring position of window position 0 = frame 16 j - 48; par = j & 1;
+	auto products = [&]<int NB> (int par, int w0, int b0, int nfl) {     // w0 = ring position of window position 0 = frame 16 j - 48; par = j & 1;
 	                                                                     // nfl = how many of this lane's four frames belong to the call
-		constexpr int NB = 2;
 		m16::BFrag B[NB];
 		float4 x0[NB];                                                   // x[n - 24] of this lane's four frames, exact
 		float un[NB];
@@ -330,6 +405,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 #pragma unroll
 		for (int n = 0; n < NB; ++n) {
 			unsigned char* const dst = vbuf + par * VBUF_B + ((4 * kg) * NCOL + 16 * (b0 + n) + cc) * 16;
+			(void) dst;
 			const float xr[4] = { x0[n].x, x0[n].y, x0[n].z, x0[n].w };
 			float pm = 0.f, px = 0.f;
 #pragma unroll
@@ -337,13 +413,45 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 				const float keep = r < nfl ? 1.f : 0.f;
 				px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
 				pm = __builtin_fmaxf (pm, max3f (fabsf (y[n][0][r]), fabsf (y[n][1][r]), fabsf (y[n][2][r])) * keep);      // truepeakdsp.cc:65
+#if MTR_TPB_FUSED && MTR_TPB_PAIRMAPS
+				{
+					const v2f W = v2f{a.w1, a.w2};
+					const v2f b1 = W * fabsf (xr[r]), b2 = W * (fabsf (y[n][0][r]) * un[n]), b3 = W * (fabsf (y[n][1][r]) * un[n]), b4 = W * (fabsf (y[n][2][r]) * un[n]);
+					const v2f d1 = max2 (b1, b2), d2 = fma2 (AA, b1, b2), e1 = max2 (b3, b4), e2 = fma2 (AA, b3, b4);
+					unsigned char* const cd = cbuf + par * CBUF_B + (((4 * kg + r) * 2) * NCOL + 16 * (b0 + n) + cc) * 16;
+					*reinterpret_cast<float4*> (cd) = float4{d1.x, d1.y, d2.x, d2.y};
+					*reinterpret_cast<float4*> (cd + NCOL * 16) = float4{e1.x, e1.y, e2.x, e2.y};
+				}
+#else
 				*reinterpret_cast<float4*> (dst + r * NCOL * 16) = float4{fabsf (xr[r]), fabsf (y[n][0][r]) * un[n], fabsf (y[n][1][r]) * un[n], fabsf (y[n][2][r]) * un[n]};
+#endif
 			}
 			pk[n] = max3f (pk[n], px, pm * un[n]);
 		}
 	};
 
-	const v2f AA = v2f{a1, a2};
+#if MTR_TPB_PAIRMAPS
+	// Two attacks in a row are z <- max (z, a z + max (b1, b2), a^2 z + (a b1 + b2)), b = w v: a frame is two such maps, one
+	// after the other on the chain (the release folded into the first one's slopes) — two intercepts per pair and filter, one
+	// fused multiply-add and one maximum each, instead of the four intercepts of the frame's single map (6 + 6).
+	auto maps = [&]<int F0, int F1> (int par) {
+		if constexpr (F1 > F0) {
+		const unsigned char* const src = vbuf + par * VBUF_B + lane * 16;
+		unsigned char* const dst = cbuf + par * CBUF_B + lane * 16;
+		const v2f W = v2f{a.w1, a.w2};
+		float4 va[F1 - F0];
+#pragma unroll
+		for (int f = F0; f < F1; ++f) va[f - F0] = *reinterpret_cast<const float4*> (src + f * NCOL * 16);
+#pragma unroll
+		for (int f = F0; f < F1; ++f) {
+			const v2f b1 = W * va[f - F0].x, b2 = W * va[f - F0].y, b3 = W * va[f - F0].z, b4 = W * va[f - F0].w;
+			const v2f d1 = max2 (b1, b2), d2 = fma2 (AA, b1, b2), e1 = max2 (b3, b4), e2 = fma2 (AA, b3, b4);
+			*reinterpret_cast<float4*> (dst + (f * 2 + 0) * NCOL * 16) = float4{d1.x, d1.y, d2.x, d2.y};
+			*reinterpret_cast<float4*> (dst + (f * 2 + 1) * NCOL * 16) = float4{e1.x, e1.y, e2.x, e2.y};
+		}
+		}
+	};
+#else
 	auto maps = [&]<int F0, int F1> (int par) {
 		if constexpr (F1 > F0) {
 		const unsigned char* const src = vbuf + par * VBUF_B + lane * 16;
@@ -367,6 +475,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		}
 		}
 	};
+#endif
 
 	// ---- prologue: the 48 frames before the call (47 of history; frame -48 is never multiplied by a non-zero tap) and chunk 0 ----
 	if (wid != 0) {
@@ -378,7 +487,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 				x = a.hist[((size_t) s * MTR_FIR_HALO + (size_t) (i - 1)) * 2 + (C == 2 ? (col >> 5) : 0)];
 			ring[col * RSTRIDE + 32 + i] = x;
 		}
-		if (wid == 3) { fetch (0); put (0); }
+		if (wid == 3) fetch_put_ragged (0, 0);
 	}
 	if (threadIdx.x < 2) flag_sh[threadIdx.x] = 0;
 	__syncthreads ();
@@ -392,6 +501,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		write_slot (32, x[0]); write_slot (48, x[1]); write_slot (64, x[2]); write_slot (0, x[3]);
 		un_sh[lane] = cs.un;
 		hm3 = hm2; hm2 = hm1; hm1 = m0;
+		if (dma_ok && !MTR_TPB_DBG_NOFETCH) {                           // chunks 1 and 2: on their way before the loop starts
+			if (2 * F <= n_frames) dma (1, 1);
+			if (3 * F <= n_frames) dma (2, 2);
+		}
 	}
 	__syncthreads ();
 
@@ -404,6 +517,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	v2f sl2[5];
 #pragma unroll
 	for (int k = 0; k < 5; ++k) sl2[k] = v2f{s1[k], s2[k]};
+	const v2f AA2 = v2f{(float) ((double) a1 * (double) a1), (float) ((double) a2 * (double) a2)};   // (pair maps: the second pair's slopes are a, a^2)
+	(void) AA2;
 	auto chain = [&]<bool FULL> (int par, int nf) {
 		const unsigned char* const src = cbuf + par * CBUF_B + lane * 16;
 		float4 q1[F], q2[F];                                             // the maps do not depend on the state: all sixteen frames' reads go out first
@@ -415,6 +530,14 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 #pragma unroll
 		for (int f = 0; f < F; ++f) {
 			if (FULL || f < nf) {                                            // wave-uniform: only the call's last chunk is short
+#if MTR_TPB_PAIRMAPS
+				const v2f u0 = sl2[0] * zz, u1 = fma2 (sl2[1], zz, v2f{q1[f].x, q1[f].y}), u2 = fma2 (sl2[2], zz, v2f{q1[f].z, q1[f].w});
+				const v2f zh = v2f{max3f (u0.x, u1.x, u2.x), max3f (u0.y, u1.y, u2.y)};
+				const v2f w1_ = fma2 (AA, zh, v2f{q2[f].x, q2[f].y}), w2_ = fma2 (AA2, zh, v2f{q2[f].z, q2[f].w});
+				zz = v2f{max3f (zh.x, w1_.x, w2_.x), max3f (zh.y, w1_.y, w2_.y)};
+				zm = __builtin_fmaxf (zm, zz.x + zz.y);
+				continue;
+#endif
 				const v2f t0 = sl2[0] * zz, t1 = fma2 (sl2[1], zz, v2f{q1[f].x, q1[f].y}), t2 = fma2 (sl2[2], zz, v2f{q1[f].z, q1[f].w}),
 				          t3 = fma2 (sl2[3], zz, v2f{q2[f].x, q2[f].y}), t4 = fma2 (sl2[4], zz, v2f{q2[f].z, q2[f].w});
 				zz = v2f{max3f (max3f (t0.x, t1.x, t2.x), t3.x, t4.x), max3f (max3f (t0.y, t1.y, t2.y), t3.y, t4.y)};
@@ -422,53 +545,101 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 			}
 		}
 	};
+	constexpr int LAG = MTR_TPB_FUSED ? 1 : 2;                           // chunks between the products and the chains
+	// THE LOOP, once per role: every wave runs the same iterations and the same barriers, but each role's copy of the loop has
+	// its own registers (in ONE loop with the roles as branches the compiler re-fetched the products' twelve tap fragments from
+	// global memory in every iteration — the chains' thirty-two map registers were live across the same loop — and a block of
+	// products took 800 cycles, more than half of them waiting for those loads).
 	int slot_w = 32, slot_p = F % RING;                                  // window start of chunk t; where chunk t + 1 goes
-	constexpr int LAG = 2;                                               // chunks between the products and the chains
-	for (int64_t t = 0; t < n_chunks + LAG; ++t) {
-		const int par = (int) (t & 1);
-		// a column's scale moved when chunk t was split (last iteration): its older slots and its un follow now, before this
-		// iteration's products read them — the cold path, with its own barrier (the flag is uniform: every wave reads it here,
-		// and wave 3 clears it only behind that barrier)
-		const int moved = __builtin_amdgcn_readfirstlane (flag_sh[par]);
-		if (__builtin_expect (moved != 0, 0)) {
-			if (wid == 3) rescale (slot_w + 48 >= RING ? slot_w + 48 - RING : slot_w + 48);       // chunk t's own slot = the window's last
-			__syncthreads ();
-			if (wid == 3 && lane == 0) flag_sh[par] = 0;
-		}
-		PROF_NOW (c0_);
-		if (wid == 0) {
-			if (t >= LAG && !MTR_TPB_DBG_NOCHAIN) {
-				const int64_t left = n_frames - (t - LAG) * F;
-				if (left >= F) chain.template operator()<true> (par ^ (LAG & 1), F);
-				else chain.template operator()<false> (par ^ (LAG & 1), (int) left);
+	const int64_t n_it = n_chunks + LAG;
+	// iterations [t0, t1) of the loop (the parity of an iteration is a compile-time constant in `work`: the buffers it selects)
+	auto run_range = [&]<bool SPLITTER> (int64_t t0, int64_t t1, auto&& work) __attribute__ ((always_inline)) {
+		auto iteration = [&]<int PAR> (int64_t t) __attribute__ ((always_inline)) {
+			// a column's scale moved when chunk t was split (last iteration): its older slots and its un follow now, before this
+			// iteration's products read them — the cold path, with its own barrier (the flag is uniform: every wave reads it here,
+			// and wave 3 clears it only behind that barrier)
+			const int moved = __builtin_amdgcn_readfirstlane (flag_sh[PAR]);
+			if (__builtin_expect (moved != 0, 0)) {
+				if constexpr (SPLITTER) rescale (slot_w + 48 >= RING ? slot_w + 48 - RING : slot_w + 48);   // chunk t's own slot = the window's last
+				__syncthreads ();
+				if (SPLITTER && lane == 0) flag_sh[PAR] = 0;
 			}
-		} else if (wid <= 2) {
+			PROF_NOW (c0_);
+			work.template operator()<PAR> (t, slot_w, slot_p);
+			PROF_NOW (c1_);
+			__syncthreads ();
+			PROF_NOW (c2_);
+			PROF_ADD (0, c1_ - c0_); PROF_ADD (2, c2_ - c1_); PROF_ADD (3, c2_ - c0_);
+			slot_w = slot_w + F >= RING ? slot_w + F - RING : slot_w + F;
+			slot_p = slot_p + F >= RING ? slot_p + F - RING : slot_p + F;
+		};
+		for (int64_t t = t0; t < t1; ++t) {
+			if (t & 1) iteration.template operator()<1> (t);
+			else       iteration.template operator()<0> (t);
+		}
+	};
+	auto run = [&]<bool SPLITTER> (auto&& work) __attribute__ ((always_inline)) { run_range.template operator()<SPLITTER> (0, n_it, work); };
+	auto maps_of = [&]<int F0, int F1, int PAR> (int64_t t) __attribute__ ((always_inline)) {
+		if (!MTR_TPB_FUSED && t >= 1 && t - 1 < n_chunks && !MTR_TPB_DBG_NOMAPS) maps.template operator()<F0, F1> (PAR ^ 1);
+	};
+	auto run_products = [&]<int NB> (int b0) __attribute__ ((always_inline)) {
+		run.template operator()<false> ([&]<int PAR> (int64_t t, int slot_w, int) __attribute__ ((always_inline)) {
 			if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
 				const int64_t left = n_frames - t * F - 4 * kg;                 // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
-				products (par, slot_w, 2 * (wid - 1), left >= 4 ? 4 : (left > 0 ? (int) left : 0));
+				products.template operator()<NB> (PAR, slot_w, b0, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
 			}
-		} else {
-			const bool more = t + 1 < n_chunks;
-			if (wid == 3 && more && !MTR_TPB_DBG_NOFETCH) fetch (t + 1);
-			if (t >= 1 && t - 1 < n_chunks && !MTR_TPB_DBG_NOMAPS) {
-				if (wid == 4) maps.template operator()<MAPF[0], MAPF[1]> (par ^ 1);
-				else if (wid == 5) maps.template operator()<MAPF[1], MAPF[2]> (par ^ 1);
-				else if (wid == 6) maps.template operator()<MAPF[2], MAPF[3]> (par ^ 1);
-				else if (wid == 7) maps.template operator()<MAPF[3], MAPF[4]> (par ^ 1);
-				else maps.template operator()<MAPF[4], MAPF[5]> (par ^ 1);
+		});
+	};
+	auto run_maps = [&]<int I> () __attribute__ ((always_inline)) {
+		run.template operator()<false> ([&]<int PAR> (int64_t t, int, int) __attribute__ ((always_inline)) { maps_of.template operator()<MAPF[I], MAPF[I + 1], PAR> (t); });
+	};
+	if (wid == 0) {
+		run.template operator()<false> ([&]<int PAR> (int64_t t, int, int) __attribute__ ((always_inline)) {
+			if (t >= LAG && !MTR_TPB_DBG_NOCHAIN) {
+				const int64_t left = n_frames - (t - LAG) * F;
+				if (left >= F) chain.template operator()<true> (PAR ^ (LAG & 1), F);
+				else chain.template operator()<false> (PAR ^ (LAG & 1), (int) left);
 			}
-			if (wid == 3 && more && !MTR_TPB_DBG_NOFETCH) {
-				put (slot_p);
+		});
+	} else if (wid == 3) {
+		// Two loops.  The first serves the whole chunks that came by LDS-DMA, and holds NO vector-memory instruction the compiler
+		// knows of: any such load makes it count vmcnt, and its conservative waits (vmcnt (0) where paths join) would wait for the
+		// DMA in flight as well.  The second takes over where chunk t + 1 is the call's ragged last one (or for the whole call,
+		// when the streams do not start on 16 bytes) and drains the pipeline.
+		const int64_t n_whole = n_frames / F;
+		const int64_t t_dma = dma_ok && !MTR_TPB_DBG_NOFETCH ? (n_whole > 1 ? n_whole - 1 : 0) : 0;     // chunks 1 .. n_whole - 1 are staged
+		run_range.template operator()<true> (0, t_dma, [&]<int PAR> (int64_t t, int, int slot_p) __attribute__ ((always_inline)) {
+			// chunk t + 3 leaves HBM; chunk t + 1, sent three iterations ago, is split from the staging area into both rings
+			const int sb1 = (int) ((t + 1) % 3);
+			if ((t + 4) * F <= n_frames && !MTR_TPB_DBG_NODMA) dma (t + 3, sb1 == 0 ? 2 : sb1 - 1);   // (t + 3) % 3: the slot chunk t was read from, an iteration ago
+			// chunk t + 1 has landed when at most the DMA instructions of the younger chunks are outstanding
+			const int younger = ((t + 3) * F <= n_frames ? 1 : 0) + ((t + 4) * F <= n_frames ? 1 : 0);
+			if (MTR_TPB_DBG_NODMA) { }
+			else if (younger == 2) asm volatile ("s_waitcnt vmcnt(8)" ::: "memory");
+			else if (younger == 1) asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
+			else                   asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+			if (!MTR_TPB_DBG_NOSPLIT) split_staged (sb1, slot_p, PAR ^ 1);
+			maps_of.template operator()<MAPF[PW == 2 ? 4 : 2], MAPF[PW == 2 ? 5 : 3], PAR> (t);
+		});
+		run_range.template operator()<true> (t_dma, n_it, [&]<int PAR> (int64_t t, int, int slot_p) __attribute__ ((always_inline)) {
+			if (t + 1 < n_chunks && !MTR_TPB_DBG_NOFETCH) {
+				fetch_put_ragged (t + 1, slot_p);
 				wave_sync ();
-				split (slot_p, par ^ 1);
+				split (slot_p, PAR ^ 1);
 			}
-		}
-		PROF_NOW (c1_);
-		__syncthreads ();
-		PROF_NOW (c2_);
-		PROF_ADD (0, c1_ - c0_); PROF_ADD (2, c2_ - c1_); PROF_ADD (3, c2_ - c0_);
-		slot_w = slot_w + F >= RING ? slot_w + F - RING : slot_w + F;
-		slot_p = slot_p + F >= RING ? slot_p + F - RING : slot_p + F;
+			maps_of.template operator()<MAPF[PW == 2 ? 4 : 2], MAPF[PW == 2 ? 5 : 3], PAR> (t);
+		});
+	} else if constexpr (PW == 2) {
+		if (wid <= 2) run_products.template operator()<2> (2 * (wid - 1));
+		else if (wid == 4) run_maps.template operator()<0> ();
+		else if (wid == 5) run_maps.template operator()<1> ();
+		else if (wid == 6) run_maps.template operator()<2> ();
+		else run_maps.template operator()<3> ();
+	} else {
+		if (wid <= 2) run_products.template operator()<1> (wid - 1);
+		else if (wid == 5 || wid == 6) run_products.template operator()<1> (wid - 3);
+		else if (wid == 4) run_maps.template operator()<0> ();
+		else run_maps.template operator()<1> ();
 	}
 	z1 = zz.x; z2 = zz.y;
 #ifdef MTR_TPB_PROF
@@ -479,9 +650,11 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	uint32_t* const pk_sh = reinterpret_cast<uint32_t*> (ring);          // the ring is spent
 	if (wid == 0) pk_sh[lane] = 0u;
 	__syncthreads ();
-	if (wid == 1 || wid == 2) {
-		atomicMax (&pk_sh[32 * (wid - 1) + cc], __float_as_uint (pk[0]));
-		atomicMax (&pk_sh[32 * (wid - 1) + 16 + cc], __float_as_uint (pk[1]));
+	if (prod_wave) {
+		if (PW == 2) {
+			atomicMax (&pk_sh[32 * (wid - 1) + cc], __float_as_uint (pk[0]));
+			atomicMax (&pk_sh[32 * (wid - 1) + 16 + cc], __float_as_uint (pk[1]));
+		} else atomicMax (&pk_sh[16 * (wid <= 2 ? wid - 1 : wid - 3) + cc], __float_as_uint (pk[0]));
 	}
 	__syncthreads ();
 	if (wid == 0 && owner) {

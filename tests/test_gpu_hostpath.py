@@ -59,7 +59,7 @@ def _both_ways(M, x, calls, meters, fs=48000.0, chunk_streams=5, **kw):
             pos = 0
             for n in calls:
                 if host:
-                    e.set_host_chunk_bytes(chunk_streams * ((n + 1) & ~1) * C * 4)
+                    e.set_host_chunk_bytes(chunk_streams * (((n + 3) & ~3) if C == 1 else ((n + 1) & ~1)) * C * 4)
                     e.process(np.ascontiguousarray(x[:, pos:pos + n]))
                 else:
                     e.process_device(dev.data_ptr() + pos * C * 4, n, x.shape[1], st)
@@ -72,7 +72,12 @@ def _both_ways(M, x, calls, meters, fs=48000.0, chunk_streams=5, **kw):
     for a, b in zip(res, hst):
         assert a.keys() == b.keys()
         for k in a:
-            assert np.array_equal(a[k], b[k], equal_nan=True), k
+            if k in ("d_avg", "d_var_m", "d_var_s"):
+                # the SDH's double sums are grouped by the call's ALIGNMENT (16-byte loads with a scalar head): the staging buffer of
+                # the host path and a view into the resident batch start on different bytes, and the groups differ in the last bits
+                assert np.allclose(a[k], b[k], rtol=1e-11, atol=0, equal_nan=True), k
+            else:
+                assert np.array_equal(a[k], b[k], equal_nan=True), k
     return seg_r
 
 
