@@ -155,7 +155,8 @@ __device__ __forceinline__ void lo_second (uint32_t& lw, uint32_t hw, float x1)
 }
 
 // ALIGNED: the tile (a 50 ms fragment) is a whole number of steps — 48, 96, 192, 32 kHz; otherwise (44.1, 88.2 kHz: 2205, 4410 frames)
-// the step in which a tile ends runs the recurrence frame by frame, with the reference's end-of-fragment actions at the exact frame.
+// the step in which a tile ends is followed by a second run of its recurrence, frame by frame from the state the step started with,
+// with the reference's end-of-fragment actions at the exact frame (every other step is the aligned kernel's code).
 template <bool EBU, bool ALIGNED>
 __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 {
@@ -234,9 +235,16 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	// ---- K-filter warm-up of the segments that do not start the call (warm_steps is a multiple of 4) -------------------------
 	if (warm) {
 		for (uint32_t w = 0; w < a.warm_steps; w += 4) {
+			/* (the recurrence in the main loop's software-pipelined order — the x-chain of frame n + 1 between the y-chain of frame n: \
+			 * the same operations on the same operands, 5 cycles apiece instead of the 8 a dependent packed pair takes) */ \
 #define MTR_WARM(B)                                                              \
 			{                                                                        \
-				_Pragma ("unroll") for (int n = 0; n < R; ++n) kstep (kc, ks, xq[B][n]); \
+				KWork kw_;                                                           \
+				kw_.x[0] = ks.z2; kw_.x[1] = ks.z1;                                  \
+				[&]<int... Is> (std::integer_sequence<int, Is...>) __attribute__ ((always_inline)) { \
+					(kopx<kseq_tab.op[Is]> (kc, ks, kw_, xq[B], kseq_tab.frame[Is]), ...); \
+				} (std::make_integer_sequence<int, KOPS>{});                         \
+				ks.z2 = kw_.x[R]; ks.z1 = kw_.x[R + 1];                              \
 				load.template operator()<(B + 3) & 3> (); lp += R / 2;                \
 			}
 			MTR_WARM (0) MTR_WARM (1) MTR_WARM (2) MTR_WARM (3)
@@ -577,6 +585,9 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 			const bool boundary = frames_left <= R;                   // wave-uniform
 			KState at_start = ks;
 			step.template operator()<U, PROD, true> ();
+			// (the step's recurrence is needed HERE, whichever way the branch below goes: without this the compiler sinks all 176
+			// operations out of the MFMA shadows they were placed in, into the branch that uses them — one lump behind the step)
+			asm volatile ("" : "+v"(ks.z1), "+v"(ks.z2), "+v"(ks.z3), "+v"(ks.z4), "+v"(ks.sj));
 			if (boundary) { ks = at_start; kslow.template operator()<U> (); }
 			else frames_left -= R;
 		}
