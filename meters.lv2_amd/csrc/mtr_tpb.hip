@@ -12,14 +12,12 @@
 // (round 4's form; round 3's split every 64-sample window again for every 16-frame chunk — each sample four times, in
 // the lanes of the products — which made a block of products a 1600-cycle dependent sequence):
 //
-//   * `if (v > z) z += w (v - z)` is z <- max (z, a z + w v) with a = 1 - w, and FOUR of them in a row are
-//         z <- max (z, a z + c1, a^2 z + c2, a^3 z + c3, a^4 z + c4),
-//     c_k = the best intercept with k attacks among the frame's four values (c_k <- max (c_k, a c_(k-1) + w v) value
-//     by value: 6 fused multiply-adds and 6 maxima).  The c_k depend on the values only — any lane can form them,
-//     for any frame — and what is left ON the chain per frame and filter is one multiply, four INDEPENDENT fused
-//     multiply-adds of the same z (the release w3 folded into their slopes) and two v_max3: three dependent
-//     operations instead of nine.  Exact in real arithmetic; in f32 a few ulps from the reference's sequence (held
-//     to the 2e-6 of tests/test_gpu_parity.py::test_truepeak_ballistics_*).
+//   * `if (v > z) z += w (v - z)` is z <- max (z, a z + w v) with a = 1 - w: a monotone max-affine map, and maps of
+//     that kind compose.  The intercepts depend on the values only — any lane can form them, for any frame — so what is
+//     left ON the chain per frame and filter is the release, two fused multiply-adds and a v_max3, twice (the frame's
+//     four values as two pair maps, see below; round 3 applied them as one five-piece map, MTR_TPB_PAIRMAPS = 0).  Exact
+//     in real arithmetic; in f32 a few ulps from the reference's sequence (held to the 2e-6 of
+//     tests/test_gpu_parity.py::test_truepeak_ballistics_*; 600 fuzzed shapes: <= 7.4e-7 up to 48 kHz, 1.6e-6 at 192 kHz).
 //   * the interpolator is the matrix-pipe one of mtr_mfma16_fir.h (samples and taps as two f16 halves, three partial
 //     products, f32 accumulation: within 4e-7 of the exact-f32 chain): a workgroup owns 64 (stream, channel)
 //     columns = 4 blocks of 16, a chunk is 16 frames = the rows of one block.
@@ -30,12 +28,23 @@
 //     that has become 2^5 quieter than the scale was made for — the column's three older slots are rescaled in place (a
 //     power of two: exact but for what falls below f16's range, 2^-27 of the new maximum) in a cold path with its own
 //     barrier.  22 bits of every sample within 2^-11 of the window's maximum, as with a scale per window.  The products
-//     then READ their operands (four ds_read_b128 per block) instead of forming them; phase 0 (x[n - 24]) comes from the
-//     f32 ring the fetch fills, exactly.
-//   * eight waves, two per SIMD (waves w and w + 4 share one): wave 0 walks the 64 chains (chunk t - 2); waves 1 and 2 run
-//     the products of chunk t, two blocks of 18 MFMAs each, and leave the four values of every frame in LDS; wave 3
-//     fetches chunk t + 1, splits it and forms maps; waves 4 - 7 form the per-frame maps of chunk t - 1 (lane = column).
-//     Values and maps are double buffered in LDS, one barrier per chunk.
+//     then READ their operands (four ds_read_b128 per block) instead of forming them; phase 0 (x[n - 24]) comes from an
+//     f32 ring the same wave fills, exactly.
+//   * a chunk travels HBM -> LDS by LDS-DMA, three iterations ahead of its products, issued as inline assembly: the
+//     compiler's own vmcnt bookkeeping (conservative at loop back edges and where paths join, and aware that an LDS-DMA
+//     writes LDS) waited for whatever was in flight at every barrier — in rounds 2 and 3, and in this round's first four
+//     forms, the wave that fetched sat out HBM's latency in every chunk, and the whole workgroup with it at the barrier.
+//   * the lanes that produce a frame's four values form its maps as well: two attacks in a row are
+//     z <- max (z, a z + max (b1, b2), a^2 z + (a b1 + b2)), b = w v, so a frame is two such maps applied one after the
+//     other on the chain — two intercepts per pair and filter, ten instructions per frame and column instead of
+//     twenty-two for the frame's single five-piece map — written straight to where the chains read them: no values in
+//     LDS, no map waves, one chunk less between products and chains.
+//   * eight waves, each with ITS OWN copy of the loop (one loop with the roles as branches made the compiler fetch the
+//     products' tap fragments from global memory in every iteration): wave 0 walks the 64 chains (chunk t - 1); waves 1, 2,
+//     5, 6 run one block of products + maps each (chunk t; two per SIMD cover each other's latencies); wave 3 sends
+//     chunk t + 3 on its way and splits chunk t + 1; waves 4 and 7 only keep the barriers' count.  One barrier per chunk.
+//     (MTR_TPB_FUSED = 0, MTR_TPB_PROD_WAVES = 2, MTR_TPB_PAIRMAPS = 0, MTR_TPB_MAP_SPLIT, MTR_TPB_PROD_SET and the
+//     MTR_TPB_DBG_* switches build the forms this one was measured against: tools/tpb_prof.hip, profiles/r04_tpb.md.)
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -121,6 +130,11 @@ static_assert (LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 #endif
 constexpr int MAPF[6] = { MTR_TPB_MAP_SPLIT };
 constexpr int PW = MTR_TPB_PROD_WAVES;
+// PW == 4: the waves that run blocks 0 .. 3 (waves w and w + 4 share a SIMD; wave 0 = the chains, wave 3 = fetch + split)
+#ifndef MTR_TPB_PROD_SET
+#define MTR_TPB_PROD_SET 1, 2, 5, 6
+#endif
+constexpr int PSET[4] = { MTR_TPB_PROD_SET };
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
 __device__ __forceinline__ v2f fma2 (v2f a, v2f b, v2f c) { return __builtin_elementwise_fma (a, b, c); }
@@ -368,7 +382,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// ---- the products (waves 1, 2: two blocks each) and the per-frame maps (lane = column) ------------------------------------
 	const int cc = lane & 15, kg = lane >> 4;
 	m16::AFrag A;
-	const bool prod_wave = wid == 1 || wid == 2 || (PW == 4 && (wid == 5 || wid == 6));
+	const int my_block = PW == 4 ? (wid == PSET[0] ? 0 : wid == PSET[1] ? 1 : wid == PSET[2] ? 2 : wid == PSET[3] ? 3 : -1) : -1;
+	const bool prod_wave = PW == 4 ? my_block >= 0 : (wid == 1 || wid == 2);
 	if (prod_wave) {
 		A.load (a.mfma_a, lane);
 		// (used — waited for — right here: a load still pending where the roles part makes the compiler guard every register it
@@ -636,9 +651,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		else if (wid == 6) run_maps.template operator()<2> ();
 		else run_maps.template operator()<3> ();
 	} else {
-		if (wid <= 2) run_products.template operator()<1> (wid - 1);
-		else if (wid == 5 || wid == 6) run_products.template operator()<1> (wid - 3);
-		else if (wid == 4) run_maps.template operator()<0> ();
+		if (my_block >= 0) run_products.template operator()<1> (my_block);
+		else if (wid == 4) run_maps.template operator()<0> ();        // (with fused maps: waves without a role only keep the barriers' count)
 		else run_maps.template operator()<1> ();
 	}
 	z1 = zz.x; z2 = zz.y;
@@ -654,7 +668,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		if (PW == 2) {
 			atomicMax (&pk_sh[32 * (wid - 1) + cc], __float_as_uint (pk[0]));
 			atomicMax (&pk_sh[32 * (wid - 1) + 16 + cc], __float_as_uint (pk[1]));
-		} else atomicMax (&pk_sh[16 * (wid <= 2 ? wid - 1 : wid - 3) + cc], __float_as_uint (pk[0]));
+		} else atomicMax (&pk_sh[16 * my_block + cc], __float_as_uint (pk[0]));
 	}
 	__syncthreads ();
 	if (wid == 0 && owner) {
