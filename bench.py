@@ -124,9 +124,9 @@ def kernel_sha():
 def committed_traffic(meters, S, T, layout):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md):
     the counters cannot be read from inside this process, so the figure is reported only for the very workload AND the
-    very kernel sources it was measured on (profiles/r03_traffic.json carries their hash); otherwise null."""
+    very kernel sources it was measured on (profiles/r04_traffic.json carries their hash); otherwise null."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
         w = tj["workload"]
         if (meters, S, T, layout) == (w["meters"], w["streams_per_gpu"], w["frames_per_stream"], w["layout"]) \
                 and tj["kernel_sha16"] == kernel_sha():
@@ -419,9 +419,9 @@ def main():
                 # an MFMA with the two full-rate (or one half-rate) VALU instructions that ride behind it issues every 19.2 cycles,
                 # the K-weighting recurrence that does not fit there (128 of its 176 packed instructions per step) runs as one
                 # packed block at 5.1 cycles per instruction + one 17-cycle wait for the matrix pipe, an LDS instruction costs 6.
-                # profiles/r03_kseg_step_cycles.txt has the measured step (4.03 k cycles; 3.11 k without the recurrence) and
-                # profiles/r03_kseg_clock.txt the clock the power cap allows under this kernel (1.56 - 1.60 GHz of 2.4) — both are
-                # properties of the committed profile, not of this run; this run contributes kernel_ms.
+                # profiles/r04_kseg_step_cycles.txt has the measured step (4.07 k cycles; 3.11 k without the recurrence) and
+                # profiles/r04a_kseg_ebu_tp.md the clock the power cap allows under this kernel (1.585 GHz of 2.4; r03: 1.56 - 1.60) —
+                # both are properties of the committed profile, not of this run; this run contributes kernel_ms.
                 steps = S * T / 1024.0
                 n_simd = 1024.0
                 ebu_on = bool(meters & M.METER_EBU)
@@ -431,7 +431,7 @@ def main():
                 out["roofline"]["binding_roofline"] = {
                     "bound": "SIMD issue cycles under the power cap: f16 MFMA (3 partial products) with two VALU riders each + the packed recurrence block + LDS",
                     "mfma_pipe_cycles_per_step": 144 * 16, "issue_model_cycles_per_step": model_step,
-                    "profiled_cycles_per_step": (4049.1 if ebu_on else 3104.7) if seg else None,
+                    "profiled_cycles_per_step": (4069.8 if ebu_on else 3113.1) if seg else None,
                     "mfma_pipe_cycles_per_simd": mfma_cycles, "issue_floor_cycles_per_simd": floor_cycles,
                     "kernel_ms_at_floor_and_2p4_ghz": floor_cycles / 2.4e6, "kernel_ms_at_floor_and_profiled_clock_1p58_ghz": floor_cycles / 1.58e6,
                     "frac_of_floor_at_profiled_clock": (floor_cycles / 1.58e6) / k_ms,
