@@ -39,12 +39,16 @@
 //     other on the chain — two intercepts per pair and filter, ten instructions per frame and column instead of
 //     twenty-two for the frame's single five-piece map — written straight to where the chains read them: no values in
 //     LDS, no map waves, one chunk less between products and chains.
-//   * eight waves, each with ITS OWN copy of the loop (one loop with the roles as branches made the compiler fetch the
-//     products' tap fragments from global memory in every iteration): wave 0 walks the 64 chains (chunk t - 1); waves 1, 2,
-//     5, 6 run one block of products + maps each (chunk t; two per SIMD cover each other's latencies); wave 3 sends
-//     chunk t + 3 on its way and splits chunk t + 1; waves 4 and 7 only keep the barriers' count.  One barrier per chunk.
-//     (MTR_TPB_FUSED = 0, MTR_TPB_PROD_WAVES = 2, MTR_TPB_PAIRMAPS = 0, MTR_TPB_MAP_SPLIT, MTR_TPB_PROD_SET and the
-//     MTR_TPB_DBG_* switches build the forms this one was measured against: tools/tpb_prof.hip, profiles/r04_tpb.md.)
+//   * twelve waves, three per SIMD (156 registers), each with ITS OWN copy of the loop (one loop with the roles as branches
+//     made the compiler fetch the products' tap fragments from global memory in every iteration): wave 0 walks the 64 chains
+//     (chunk t - 1); a block's products run as TWO units on two waves — unit A: phase 1 (6 MFMAs) and the frame's first
+//     pair map (x[n - 24], y1), unit B: phases 2 and 3 (12 MFMAs) and the second — the B units on waves 1, 5, 2, 6, the A
+//     units on waves 4, 9, 10, 7 (two B and an A on SIMDs 1 and 2, an A beside the chains, an A beside the split); wave 3
+//     sends chunk t + 3 on its way and splits chunk t + 1; waves 8 and 11 only keep the barriers' count.  One barrier per
+//     chunk; the chains (~1400 cycles per chunk) are what bounds it now.
+//     (MTR_TPB_PROD_WAVES = 4 / 2, MTR_TPB_FUSED = 0, MTR_TPB_PAIRMAPS = 0, MTR_TPB_MAP_SPLIT, MTR_TPB_PROD_SET, MTR_TPB_UNIT_*_SET,
+//     MTR_TPB_CHAIN_PRIO and the MTR_TPB_DBG_* switches build the forms this one was measured against: tools/tpb_prof.hip,
+//     profiles/r04_tpb.md, r04_tpb_experiments.md.)
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -54,7 +58,7 @@ typedef float v2f __attribute__ ((ext_vector_type (2)));
 
 // tools/tpb_prof.hip builds this file with MTR_TPB_PROF: cycles per wave and section for workgroup 0
 #ifdef MTR_TPB_PROF
-__device__ unsigned long long g_tpb_prof[8][4];
+__device__ unsigned long long g_tpb_prof[12][4];
 #define PROF_NOW(v) unsigned long long v; asm volatile ("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
 #define PROF_ADD(i, d) pr[i] += (d)
 #else
@@ -95,7 +99,12 @@ __device__ unsigned long long g_tpb_prof[8][4];
 
 namespace {
 
-constexpr int NW = 8;                          // wave 0: the chains; 1, 2: products; 3: fetch + split + maps; 4 - 7: maps
+#ifndef MTR_TPB_PROD_WAVES
+#define MTR_TPB_PROD_WAVES 8
+#endif
+// MTR_TPB_PROD_WAVES = 8 (needs MTR_TPB_FUSED): twelve waves, three per SIMD, and a block's products in TWO units on two waves —
+// unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1); unit B: phases 2 and 3 (12 MFMAs) and the second
+constexpr int NW = MTR_TPB_PROD_WAVES == 8 ? 12 : 8;   // wave 0: the chains; wave 3: fetch + split; the others: products (+ maps) or idle
 constexpr int F = 16;                          // frames per chunk = rows of one MFMA block
 constexpr int NCOL = 64;                       // (stream, channel) columns per workgroup: 32 stereo or 64 mono streams
 constexpr int RING = 5 * F;                    // samples per column: the 64-sample window of a chunk + the chunk being fetched
@@ -118,9 +127,6 @@ static_assert (LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 // MTR_TPB_PROD_WAVES = 2: waves 1, 2 run two blocks of products each; waves 4, 5, 6, 7, 3 the maps of MAPF[0..1), [1..2), ... [4..5)
 //                    = 4: waves 1, 2, 5, 6 run one block each (two products waves per SIMD cover each other's latencies);
 //                         waves 4, 7, 3 the maps of MAPF[0..1), [1..2), [2..3)
-#ifndef MTR_TPB_PROD_WAVES
-#define MTR_TPB_PROD_WAVES 4
-#endif
 #ifndef MTR_TPB_MAP_SPLIT
 #if MTR_TPB_PROD_WAVES == 2
 #define MTR_TPB_MAP_SPLIT 0, 2, 6, 10, 13, 16
@@ -135,6 +141,15 @@ constexpr int PW = MTR_TPB_PROD_WAVES;
 #define MTR_TPB_PROD_SET 1, 2, 5, 6
 #endif
 constexpr int PSET[4] = { MTR_TPB_PROD_SET };
+// PW == 8: the waves of unit A (phase 1) and unit B (phases 2, 3) of blocks 0 .. 3: three waves per SIMD (w % 4), the 30 MFMAs of
+// two B units and an A unit on SIMDs 1 and 2, an A unit beside the chains and one beside the split
+#ifndef MTR_TPB_UNIT_A_SET
+#define MTR_TPB_UNIT_A_SET 4, 9, 10, 7
+#endif
+#ifndef MTR_TPB_UNIT_B_SET
+#define MTR_TPB_UNIT_B_SET 1, 5, 2, 6
+#endif
+constexpr int ASET[4] = { MTR_TPB_UNIT_A_SET }, BSET[4] = { MTR_TPB_UNIT_B_SET };
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
 __device__ __forceinline__ v2f fma2 (v2f a, v2f b, v2f c) { return __builtin_elementwise_fma (a, b, c); }
@@ -382,8 +397,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// ---- the products (waves 1, 2: two blocks each) and the per-frame maps (lane = column) ------------------------------------
 	const int cc = lane & 15, kg = lane >> 4;
 	m16::AFrag A;
-	const int my_block = PW == 4 ? (wid == PSET[0] ? 0 : wid == PSET[1] ? 1 : wid == PSET[2] ? 2 : wid == PSET[3] ? 3 : -1) : -1;
-	const bool prod_wave = PW == 4 ? my_block >= 0 : (wid == 1 || wid == 2);
+	const int unit_a = PW == 8 ? (wid == ASET[0] ? 0 : wid == ASET[1] ? 1 : wid == ASET[2] ? 2 : wid == ASET[3] ? 3 : -1) : -1;
+	const int unit_b = PW == 8 ? (wid == BSET[0] ? 0 : wid == BSET[1] ? 1 : wid == BSET[2] ? 2 : wid == BSET[3] ? 3 : -1) : -1;
+	const int my_block = PW == 4 ? (wid == PSET[0] ? 0 : wid == PSET[1] ? 1 : wid == PSET[2] ? 2 : wid == PSET[3] ? 3 : -1) : PW == 8 ? (unit_a >= 0 ? unit_a : unit_b) : -1;
+	const bool prod_wave = PW == 2 ? (wid == 1 || wid == 2) : my_block >= 0;
 	if (prod_wave) {
 		A.load (a.mfma_a, lane);
 		// (used — waited for — right here: a load still pending where the roles part makes the compiler guard every register it
@@ -443,6 +460,61 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 			}
 			pk[n] = max3f (pk[n], px, pm * un[n]);
 		}
+	};
+
+	// PW == 8: one of the two units of a block (UB = false: phase 1 + the first pair map; true: phases 2, 3 + the second)
+	auto unit = [&]<bool UB> (int par, int w0, int b, int nfl) __attribute__ ((always_inline)) {
+		int q0 = (w0 >> 3) + kg; q0 -= q0 >= 10 ? 10 : 0;
+		int q1 = q0 + 4; q1 -= q1 >= 10 ? 10 : 0;
+		const int col = 16 * b + cc;
+		const unsigned char* const h = ringh + col * HSTRIDE;
+		const unsigned char* const l = ringl + col * HSTRIDE;
+		m16::BFrag B;
+		B.h0 = *reinterpret_cast<const uint4*> (h + 16 * q0);
+		B.h1 = *reinterpret_cast<const uint4*> (h + 16 * q1);
+		B.l0 = *reinterpret_cast<const uint4*> (l + 16 * q0);
+		B.l1 = *reinterpret_cast<const uint4*> (l + 16 * q1);
+		float4 x0 = float4{0.f, 0.f, 0.f, 0.f};
+		if (!UB) { int o0 = w0 + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0; x0 = *reinterpret_cast<const float4*> (ring + col * RSTRIDE + o0); }
+		const float un = un_sh[col];
+		constexpr int P0 = UB ? 1 : 0, NPH = UB ? 2 : 1;
+		m16::f4 y[NPH];
+#pragma unroll
+		for (int p = 0; p < NPH; ++p) y[p] = m16::f4{0.f, 0.f, 0.f, 0.f};
+		// (the order of m16::block: consecutive MFMAs write different accumulators where there are two)
+#pragma unroll
+		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 0) * 2 + 0], B.h0, y[p]);
+#pragma unroll
+		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 1) * 2 + 0], B.h1, y[p]);
+#pragma unroll
+		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 0) * 2 + 0], B.l0, y[p]);
+#pragma unroll
+		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 1) * 2 + 0], B.l1, y[p]);
+#pragma unroll
+		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 0) * 2 + 1], B.h0, y[p]);
+#pragma unroll
+		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 1) * 2 + 1], B.h1, y[p]);
+		const float xr[4] = { x0.x, x0.y, x0.z, x0.w };
+		const v2f W = v2f{a.w1, a.w2};
+		float pm = 0.f, px = 0.f;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const float keep = r < nfl ? 1.f : 0.f;
+			unsigned char* const cd = cbuf + par * CBUF_B + (((4 * kg + r) * 2 + (UB ? 1 : 0)) * NCOL + col) * 16;
+			if (!UB) {
+				px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
+				pm = __builtin_fmaxf (pm, fabsf (y[0][r]) * keep);
+				const v2f b1 = W * fabsf (xr[r]), b2 = W * (fabsf (y[0][r]) * un);
+				const v2f d1 = max2 (b1, b2), d2 = fma2 (AA, b1, b2);
+				*reinterpret_cast<float4*> (cd) = float4{d1.x, d1.y, d2.x, d2.y};
+			} else {
+				pm = __builtin_fmaxf (pm, __builtin_fmaxf (fabsf (y[0][r]), fabsf (y[NPH - 1][r])) * keep);
+				const v2f b3 = W * (fabsf (y[0][r]) * un), b4 = W * (fabsf (y[NPH - 1][r]) * un);
+				const v2f e1 = max2 (b3, b4), e2 = fma2 (AA, b3, b4);
+				*reinterpret_cast<float4*> (cd) = float4{e1.x, e1.y, e2.x, e2.y};
+			}
+		}
+		pk[0] = max3f (pk[0], px, pm * un);
 	};
 
 #if MTR_TPB_PAIRMAPS
@@ -609,6 +681,9 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		run.template operator()<false> ([&]<int PAR> (int64_t t, int, int) __attribute__ ((always_inline)) { maps_of.template operator()<MAPF[I], MAPF[I + 1], PAR> (t); });
 	};
 	if (wid == 0) {
+#ifdef MTR_TPB_CHAIN_PRIO
+		__builtin_amdgcn_s_setprio (MTR_TPB_CHAIN_PRIO);              // (the chains are the one serial role: let them issue first on their SIMD)
+#endif
 		run.template operator()<false> ([&]<int PAR> (int64_t t, int, int) __attribute__ ((always_inline)) {
 			if (t >= LAG && !MTR_TPB_DBG_NOCHAIN) {
 				const int64_t left = n_frames - (t - LAG) * F;
@@ -650,6 +725,19 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		else if (wid == 5) run_maps.template operator()<1> ();
 		else if (wid == 6) run_maps.template operator()<2> ();
 		else run_maps.template operator()<3> ();
+	} else if constexpr (PW == 8) {
+		static_assert (PW != 8 || (MTR_TPB_FUSED && MTR_TPB_PAIRMAPS), "the two-unit form writes pair maps");
+		auto run_unit = [&]<bool UB> (int b) __attribute__ ((always_inline)) {
+			run.template operator()<false> ([&]<int PAR> (int64_t t, int slot_w, int) __attribute__ ((always_inline)) {
+				if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
+					const int64_t left = n_frames - t * F - 4 * kg;
+					unit.template operator()<UB> (PAR, slot_w, b, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
+				}
+			});
+		};
+		if (unit_a >= 0) run_unit.template operator()<false> (unit_a);
+		else if (unit_b >= 0) run_unit.template operator()<true> (unit_b);
+		else run_maps.template operator()<0> ();                      // (idle: keeps the barriers' count)
 	} else {
 		if (my_block >= 0) run_products.template operator()<1> (my_block);
 		else if (wid == 4) run_maps.template operator()<0> ();        // (with fused maps: waves without a role only keep the barriers' count)

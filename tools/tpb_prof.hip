@@ -40,7 +40,7 @@ int main (int argc, char** argv)
 	hipEventRecord (e1);
 	hipDeviceSynchronize ();
 	float ms; hipEventElapsedTime (&ms, e0, e1);
-	unsigned long long pr[8][4];
+	unsigned long long pr[12][4];
 	hipMemcpyFromSymbol (pr, HIP_SYMBOL (g_tpb_prof), sizeof pr);
 	const double nchunk = (double) ((T + F - 1) / F + 2);
 	printf ("stride %llu frames (= 128 B x %.3f): ", (unsigned long long) ST, ST * 8 / 128.0);
