@@ -589,8 +589,9 @@ def main():
             _, _, bk, w, _ = timed(S, T, M.METER_TPBALLIST, steps=2)
             cfgs["true-peak ballistics (TruePeakdsp::process), 8192 streams x 10 s"] = {
                 "kernel": "k_tpb", "kernel_ms": bk, "wall_ms": w, "frac": frac(S, T, bk),
-                "bound": "the busiest SIMD pair of a workgroup (four blocks of matrix-pipe products + per-frame max-affine maps on three SIMDs beside "
-                         "the serial chains: 3 dependent operations per frame and channel; DESIGN.md 3.5)"}
+                "bound": "the serial chains: one wave walks a workgroup's 64 (stream, channel) chains, ~1400 cycles per 16-frame chunk (two pair maps per "
+                         "frame on the critical path); the products (two units per block on two waves), the split and the LDS-DMA fetch run "
+                         "beside it (DESIGN.md 3.5)"}
             extra["configs"] = cfgs
             # SURVEY.md 8d "Timing": the end-to-end figure of a host whose audio is NOT resident — pageable host memory through
             # mtr_engine_process_host (chunks of streams: chunk k + 1 crosses the link under the kernels of chunk k) — next to a

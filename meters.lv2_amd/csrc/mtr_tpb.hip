@@ -114,7 +114,7 @@ constexpr int HSTRIDE = 176;                   // bytes per column and array of 
                                                // 11 c mod 16 is a permutation — sixteen columns' pieces sit in sixteen bank groups
 constexpr int HRING_B = NCOL * HSTRIDE;        // one array: hi | lo
 constexpr int AUX_B = 512;                     // float un [NCOL]; int flag [2]
-constexpr int VBUF_B = F * NCOL * 16;          // a chunk of values: [frame][column] x (|x[n - 24]|, |y1|, |y2|, |y3|)
+constexpr int VBUF_B = MTR_TPB_FUSED ? 0 : F * NCOL * 16;   // a chunk of values: [frame][column] x (|x[n - 24]|, |y1|, |y2|, |y3|) — only where map waves read them
 constexpr int CBUF_B = F * 2 * NCOL * 16;      // a chunk of maps: [frame][half][column] x (c_k of filter 1, of filter 2) for k = 1, 2 | 3, 4
 constexpr int STG_B = 3 * 4 * 64 * 16;         // three chunks in flight from HBM, as the LDS-DMA leaves them: [chunk][piece 64 i + lane] x 16 bytes
 constexpr int LDS_BYTES = RING_B + 2 * HRING_B + AUX_B + 2 * VBUF_B + 2 * CBUF_B + STG_B;

@@ -82,6 +82,18 @@ def test_bad_arguments_are_rejected():
     assert M.lib.mtr_band_coef(48000.0, 30, np.zeros(36).ctypes.data) == -1
     assert M.lib.mtr_engine_create(None, None) == -1
     assert b"mtr_engine_create" in M.lib.mtr_last_error()
+    # a configuration of another ABI's size is refused by the planner as by create ()
+    import ctypes as C
+    from meters.lv2_amd import engine as E
+    cfg = E._Config(struct_size=C.sizeof(E._Config) - 4, meters=3, n_streams=8, n_channels=2, sample_rate=48000.0)
+    info = E.PlanInfo()
+    assert M.lib.mtr_plan_query(C.byref(cfg), 0, 48000, 0, C.byref(info)) == -1
+    assert b"struct_size" in M.lib.mtr_last_error()
+    cfg.struct_size = C.sizeof(E._Config)
+    assert M.lib.mtr_plan_query(C.byref(cfg), 0, 48000, 0, C.byref(info)) == 0
+    # the per-call timing getter and the host-path chunk size need an engine
+    assert M.lib.mtr_engine_timing_calls(None, None, 0, None) == -1
+    assert M.lib.mtr_engine_set_host_chunk_bytes(None, 1 << 20) == -1
 
 
 def test_no_cpu_fallback():

@@ -45,7 +45,7 @@ int main (int argc, char** argv)
 	const double nchunk = (double) ((T + F - 1) / F + 2);
 	printf ("stride %llu frames (= 128 B x %.3f): ", (unsigned long long) ST, ST * 8 / 128.0);
 	printf ("S=%u T=%llu: %.3f ms, %.0f ns per chunk of %d frames\n", S, (unsigned long long) T, ms, ms * 1e6 / nchunk, F);
-	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (wave 0: the chains; 1, 2: two blocks of products each; 3: fetch + split + maps; 4 - 7: maps — MTR_TPB_MAP_SPLIT)\n");
+	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (default build — wave 0: the chains; 3: LDS-DMA + split; 1, 5, 2, 6: unit B of blocks 0 .. 3 (phases 2, 3 + second pair map); 4, 9, 10, 7: unit A (phase 1 + first pair map); 8, 11 idle)\n");
 	for (int w = 0; w < NW; ++w) printf ("  %2d  %7.1f  %7.1f  %7.1f\n", w, pr[w][0] / nchunk, pr[w][2] / nchunk, pr[w][3] / nchunk);
 	return 0;
 }
