@@ -272,54 +272,19 @@ def main():
     eng = M.Engine(S, fs, meters, n_channels=1 if mono else 2, device=local, tune_run=args.run,
                    tune_segments=args.segments, tune_layout=args.layout, tune_fir=args.fir, tune_prune=args.prune)
     eng.integr_start()
-    # The job's communicator: RCCL behind the C ABI.  Every rank is past its allocations and its first kernels (a barrier on
-    # both sides of the collective ncclCommInitRank), and the ranks AGREE on how they reduce: one rank on a fallback would
-    # leave the others inside ncclAllReduce.  Fallbacks, in order: a torch.distributed NCCL (= RCCL) group, then gloo on
-    # the same device buffers (a host hop for 6 KB; what the shared-GPU rehearsal ends up with).
-    def agreed(ok):
-        if world == 1:
-            return bool(ok)
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(int(t.item()))
-
-    comm, group, err = None, None, None
-    collective = "RCCL behind the C ABI (mtr_engine_reduce)"
+    # The job's communicator: RCCL behind the C ABI.  Every rank is past its allocations and its first kernels, and the ranks
+    # AGREE on how they reduce (meters.lv2_amd.dist.agree_on_collective: a vote over the gloo control plane; fallbacks: a
+    # torch.distributed NCCL (= RCCL) group, then gloo on the same device buffers — what the shared-GPU rehearsal ends up with).
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    if shared and os.environ.get("MTR_BENCH_TRY_RCCL") != "1":
-        err = "not tried (MTR_BENCH_SHARED_GPU)"
-    else:
-        try:
-            comm = mdist.make_comm(rank, world, local)
-        except Exception as ex:                                   # noqa: BLE001 — reported in config.collective, never silent
-            err = ex
-    if world == 1 and err:
-        raise err
-    if world > 1 and not agreed(err is None):
-        if comm is not None:
-            comm.close()
-            comm = None
-        why = "mtr_comm_init failed on a rank: %s" % (err or "another rank")
-        ok = False
-        if not shared:
-            try:
-                group = dist.new_group(backend="nccl")           # "nccl" is RCCL on ROCm
-                probe = torch.ones(1, dtype=torch.int32, device=dev)
-                dist.all_reduce(probe, group=group)
-                ok = int(probe.item()) == world
-            except Exception as ex:                               # noqa: BLE001
-                why += "; torch NCCL group: %r" % (ex,)
-            ok = agreed(ok)
-        if ok:
-            collective = "torch.distributed all_reduce over a NCCL (= RCCL) group (%s)" % why
-        else:
-            group = None
-            collective = "torch.distributed all_reduce over gloo, device buffers through the host (%s)" % why
-        print("bench.py: rank %d: %s" % (rank, collective), file=sys.stderr)
-    if world > 1:
-        dist.barrier()
+
+    def make():
+        if shared and os.environ.get("MTR_BENCH_TRY_RCCL") != "1":
+            raise RuntimeError("not tried (MTR_BENCH_SHARED_GPU)")
+        return mdist.make_comm(rank, world, local)
+
+    comm, group, collective = mdist.agree_on_collective(
+        rank, world, make, device=dev, allow_nccl=not shared,
+        log=lambda d: print("bench.py: rank %d: %s" % (rank, d), file=sys.stderr))
 
     def step():
         if mono:

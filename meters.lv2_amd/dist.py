@@ -39,6 +39,64 @@ def make_comm(rank, world, device=0):
     return _engine.Comm(rank, world, uid[0], device)
 
 
+def agree_on_collective(rank, world, make, device=None, allow_nccl=True, log=None):
+    """How the ranks of a job reduce — decided TOGETHER, so that no rank ever sits alone inside a collective.
+
+    `make()` builds this rank's engine communicator (mtr_comm_init behind it: itself a collective call) or raises.  Every
+    rank is here before anyone starts (a barrier on both sides); then the ranks vote (MIN over "mine succeeded", on CPU
+    tensors: the process group is the control plane, gloo).  All succeeded -> (comm, None, "RCCL behind the C ABI ...").
+    Otherwise every rank closes what it built and the ranks fall back, in order: a torch.distributed NCCL (= RCCL) group,
+    probed with one all-reduce on `device` and voted on the same way (skipped where allow_nccl is False: two ranks on one
+    GPU, or no GPU at all), then the default group — gloo, device buffers through the host.  Returns (comm, group,
+    description); the description names the fallback and why."""
+    import torch
+    import torch.distributed as dist
+
+    def agreed(ok):
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    comm, err = None, None
+    if world > 1:
+        dist.barrier()
+    try:
+        comm = make()
+    except Exception as ex:                                       # noqa: BLE001 — reported in the description, never silent
+        err = ex
+    if world == 1:
+        if err:
+            raise err
+        return comm, None, "RCCL behind the C ABI (mtr_engine_reduce)"
+    if agreed(err is None):
+        dist.barrier()
+        return comm, None, "RCCL behind the C ABI (mtr_engine_reduce)"
+    if comm is not None:
+        comm.close()
+    why = "mtr_comm_init failed on a rank: %s" % (err or "another rank")
+    group, ok = None, False
+    if allow_nccl:
+        try:
+            group = dist.new_group(backend="nccl")               # "nccl" is RCCL on ROCm
+            probe = torch.ones(1, dtype=torch.int32, device=device)
+            dist.all_reduce(probe, group=group)
+            ok = int(probe.item()) == world
+        except Exception as ex:                                   # noqa: BLE001
+            why += "; torch NCCL group: %r" % (ex,)
+        ok = agreed(ok)
+    if ok:
+        desc = "torch.distributed all_reduce over a NCCL (= RCCL) group (%s)" % why
+    else:
+        group = None
+        desc = "torch.distributed all_reduce over gloo, device buffers through the host (%s)" % why
+    if log:
+        log(desc)
+    dist.barrier()
+    return None, group, desc
+
+
 def programme_summary(hist, maxv):
     """Programme-level record from the reduced aggregates: integrated loudness and range exactly as
     Ebu_r128_hist::calc_integ / calc_range compute them from a histogram (ebu_r128_proc.cc:105-150)."""

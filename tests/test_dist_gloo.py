@@ -72,3 +72,51 @@ def test_two_rank_reduce_equals_single_process(tmp_path):
     assert got["rec"] == want
     assert got["shard"] == (0, 3)
     assert -30 < want["integrated"] < 0 and want["hist_M_count"] == n_total * 80
+
+
+class _FakeComm:
+    closed = 0
+
+    def close(self):
+        _FakeComm.closed += 1
+
+
+def _agree_worker(rank, world, port, scenario, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path[:0] = [ROOT, HERE]
+    from meters.lv2_amd import dist as mdist
+
+    def make():
+        if scenario == "one-fails" and rank == 1 or scenario == "all-fail":
+            raise RuntimeError("ncclCommInitRank: refused (rank %d)" % rank)
+        return _FakeComm()
+
+    comm, group, desc = mdist.agree_on_collective(rank, world, make, allow_nccl=False)
+    # whatever was agreed, the ranks reduce the same way: a collective on the default group must still work
+    t = torch.tensor([rank + 1], dtype=torch.int32)
+    mdist.all_reduce_aggregate(t, torch.zeros(1), group)
+    torch.save(dict(comm=comm is not None, group=group is not None, desc=desc, closed=_FakeComm.closed, sum=int(t.item())),
+               out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scenario", ["all-succeed", "one-fails", "all-fail"])
+def test_ranks_agree_on_how_they_reduce(tmp_path, scenario):
+    """bench.py's negotiation at N > 1 (meters.lv2_amd.dist.agree_on_collective), on two gloo ranks without a GPU: the
+    engine communicator is kept only if EVERY rank built one; a rank whose mtr_comm_init succeeded while another's failed
+    closes it and falls back with the others (it would otherwise wait inside ncclAllReduce for a peer that never comes)."""
+    out = str(tmp_path / scenario)
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_agree_worker, args=(2, port, scenario, out), nprocs=2, join=True)
+    r = [torch.load(out + ".%d" % k, weights_only=False) for k in range(2)]
+    assert r[0]["sum"] == r[1]["sum"] == 3
+    if scenario == "all-succeed":
+        assert all(x["comm"] and not x["group"] and "RCCL behind the C ABI" in x["desc"] for x in r)
+        assert r[0]["closed"] == r[1]["closed"] == 0
+    else:
+        assert not any(x["comm"] or x["group"] for x in r)
+        assert all("gloo" in x["desc"] and "mtr_comm_init failed on a rank" in x["desc"] for x in r)
+        assert r[0]["closed"] == (1 if scenario == "one-fails" else 0) and r[1]["closed"] == 0   # rank 0 built one, and gave it up
