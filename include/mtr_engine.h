@@ -134,7 +134,9 @@ int  mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_
  * exact — bit for bit what mtr_engine_process_device gives on the same audio), chunk k + 1 on a copy stream under the kernels
  * of chunk k, through two device buffers of one chunk each.  Host-link-bound: end to end at the link's rate (bench.py
  * reports it as extra.end_to_end_host, never as `value`).  Returns when the caller's memory has been read; the kernels
- * may still run (mtr_engine_sync / the result getters wait). */
+ * may still run (mtr_engine_sync / the result getters wait).  Argument errors are reported before anything is queued; a
+ * HIP failure in the middle of a call (MTR_ERR_HIP / MTR_ERR_NOMEM) leaves the chunks already queued metered and the
+ * rest not — the streams are no longer in lock step: mtr_engine_reset () before the engine is used again. */
 int  mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_frames,
                               uint64_t stream_stride_frames);
 /* Bytes of audio per chunk of mtr_engine_process_host (0 = the default, 256 MiB; at least one stream per chunk). */
