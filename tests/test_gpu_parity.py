@@ -511,6 +511,33 @@ def test_truepeak_ballistics_column_scale_moves(M, oracle):
                 assert abs(gp - pp) <= 4e-6 * pp + 1e-37, (s, ch, i, gp, pp)
 
 
+@pytest.mark.parametrize("chn", [2, 1])
+def test_truepeak_ballistics_fetch_paths_agree(M, chn):
+    """k_tpb brings whole chunks in by LDS-DMA (16-byte aligned streams) and everything else — a batch whose streams start
+    on 4 or 8 bytes (odd stride, a view into a larger buffer), the call's ragged last chunk — by plain loads: the same
+    samples either way, so level and peak must be the same bits."""
+    import torch
+    S, T = 37, 5003
+    x = np.stack([sig.lcg_noise(T, 60 + s, 2.0 ** -(s % 5)) for s in range(S)])
+    if chn == 1:
+        x = np.ascontiguousarray(x[:, :, 0])
+    st = torch.cuda.current_stream().cuda_stream
+    got = []
+    for stride, off in ((T + 3 if chn == 1 else T, 0), (T + 5, 2 if chn == 2 else 1), (T + (8 - T % 8), 0)):     # no DMA (stride); no DMA (base); DMA
+        flat = torch.zeros(S * stride * chn + 8, dtype=torch.float32, device="cuda")
+        view = flat[off:off + S * stride * chn].view(S, stride, chn) if chn == 2 else flat[off:off + S * stride].view(S, stride)
+        view[:, :T] = torch.from_numpy(x).cuda()
+        with M.Engine(S, 48000.0, M.METER_TPBALLIST, n_channels=chn) as e:
+            rec = []
+            for lo, hi in ((0, 1600), (1600, 1617), (1617, T)):
+                e.process_device(flat.data_ptr() + 4 * (off + lo * chn), hi - lo, stride, st)
+                r = e.results()
+                rec.append([(r[s].tpb_level[c], r[s].tpb_peak[c]) for s in range(S) for c in range(chn)])
+        got.append(np.array(rec, np.float32))
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+    assert np.all(got[0] > 0)
+
+
 def test_truepeak_ballistics_full_size_properties(M, oracle):
     """TruePeakdsp::process at the per-GPU shard of the bench (8192 streams x 10 s) through size-independent properties:
     determinism; exact x2 scaling (a power-of-two gain is exact in fp32, in the f16 split — the column's scale moves with
