@@ -648,13 +648,11 @@ static SegPlan seg_plan (const PlanCtx* e, const float* d_audio, uint64_t N, uin
 	// (a segment may start on any frame — odd strides, 2205-frame fragments, a call that starts inside a fragment: the kernel's
 	// loads only assume a frame's 8 bytes.)  The rest of an open fragment in front (`head`) and what is left behind the last whole
 	// fragment go to k_kwtp16, in stream order.  A tile that is not a whole number of steps (44.1 / 88.2 kHz) lets a lane read up
-	// to 15 frames past its last tile: they must be frames of this call (the tail's).
+	// to 15 frames past its last tile — the next segment's; the lanes of a stream's last segment stop at the frame (mtr_seg.hip).
 	const uint64_t head = e->frcnt != e->fragm ? e->frcnt : 0;
 	if (head >= N) return sp;
 	const uint64_t Nb = N - head;
-	const bool whole = e->fragm % MTR_SEG_STEP == 0;
-	uint64_t tiles = Nb / e->fragm;
-	if (!whole && tiles && tiles * e->fragm + MTR_SEG_STEP > Nb) --tiles;
+	const uint64_t tiles = Nb / e->fragm;
 	if (tiles == 0 || tiles > 0x7fffffffull / (e->fragm / MTR_SEG_STEP + 1)) return sp;
 	sp.head = (uint32_t) head;
 	const double spt = (double) e->fragm / MTR_SEG_STEP;

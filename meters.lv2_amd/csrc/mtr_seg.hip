@@ -178,6 +178,15 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	mtr_stream_state* const st = a.state + s;
 	const int n_steps = (int) (((uint64_t) a.n_main * a.tile_frames + R - 1) / R);   // (ALIGNED: n_main tiles of spt steps)
 	const int spt = (int) (a.tile_frames / R);
+	// Unaligned tiles: a lane's last tile ends last_rows frames into the launch's last step.  What follows is the next segment's
+	// (read again there: harmless for a maximum, and the recurrence is rerun to the exact frame, below) — but behind a stream's
+	// LAST segment it is the call's tail, another stream, or nobody's memory: those lanes never read it.  The stream pointer
+	// (of every lane: the main loop stays uniform) stops one step early, the last step's frames are fetched one by one in front
+	// of it — zeros behind the tile's end in a last segment — and the rows of that step's products behind the end do not count.
+	const int last_rows = ALIGNED ? R : (int) ((uint64_t) a.n_main * a.tile_frames - (uint64_t) (n_steps - 1) * R);   // 1 .. 16, wave-uniform
+	const bool cut = last_rows < R;
+	const bool lastq = !ALIGNED && q == a.n_segs - 1;
+	const int n_loads = n_steps - (cut ? 1 : 0);                      // steps the stream pointers walk
 
 	KCoef kc;
 	kc.a0 = a.a0; kc.a1 = a.a1; kc.a2 = a.a2; kc.b1 = a.b1; kc.b2 = a.b2; kc.c3 = a.c3; kc.c4 = a.c4; kc.eps = 1e-15f;
@@ -399,19 +408,36 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		for (int p = 0; p < 3; ++p) { ma = max3abs (ma, y[p][0], y[p][1]); mb = max3abs (mb, y[p][2], y[p][3]); }
 		pm[bc >> 1][bc & 1][0] = ma; pm[bc >> 1][bc & 1][1] = mb;
 	};
+	// ... of the launch's LAST step: lane (c, kg) holds rows (= frames of the step) 4 kg .. 4 kg + 3 of column 16 b + c; where that
+	// column is the last segment of its stream, only the rows in front of its tile's end count
+	auto fold_last = [&] (const m16::f4 (&y)[3], int bc) __attribute__ ((always_inline)) {
+		if constexpr (ALIGNED) fold (y, bc);
+		else {
+			const uint32_t ucol = min (blockIdx.x * 64u + 16u * (uint32_t) (bc >> 1) + (uint32_t) cc, n_units - 1);
+			const int rows = (ucol % a.n_segs == a.n_segs - 1) ? last_rows : R;
+			float ma = pm[bc >> 1][bc & 1][0], mb = pm[bc >> 1][bc & 1][1];
+#pragma unroll
+			for (int p = 0; p < 3; ++p) {
+				ma = max3abs (ma, 4 * kg + 0 < rows ? y[p][0] : 0.f, 4 * kg + 1 < rows ? y[p][1] : 0.f);
+				mb = max3abs (mb, 4 * kg + 2 < rows ? y[p][2] : 0.f, 4 * kg + 3 < rows ? y[p][3] : 0.f);
+			}
+			pm[bc >> 1][bc & 1][0] = ma; pm[bc >> 1][bc & 1][1] = mb;
+		}
+	};
 	// the products of the call's last step (nothing left to run under them); every chunk folds its predecessor's accumulators
+	// (the first fold is still the step before's)
 	auto products = [&]<int U> () __attribute__ ((always_inline)) {
 		fetch.template operator()<U> (B0, 0);
 #pragma unroll
 		for (int bc = 0; bc < 8; bc += 2) {
 			fetch.template operator()<U> (B1, bc + 1);
 			m16::block (A, B0, y0);
-			fold (y1, (bc + 7) & 7);
+			if (bc == 0) fold (y1, 7); else fold_last (y1, bc - 1);
 			if (bc + 2 < 8) fetch.template operator()<U> (B0, bc + 2);
 			m16::block (A, B1, y1);
-			fold (y0, bc);
+			fold_last (y0, bc);
 		}
-		fold (y1, 7);
+		fold_last (y1, 7);
 	};
 
 	int tile_left = spt;
@@ -454,7 +480,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 
 		// the stream, three steps ahead (the pointer stops with the segment: the last loads re-read its last line)
 #ifndef MTR_SEG_DBG_NOADV                                         /* (elimination runs, tools/seg_ab.sh: the same line over and over) */
-		lp += (j + 3 < n_steps) ? R / 2 : 0;
+		lp += (j + 3 < (ALIGNED ? n_steps : n_loads)) ? R / 2 : 0;
 #endif
 		load.template operator()<(U + 3) & 3> ();
 		SPROF_NOW (c1_); SPROF_ADD (0, c1_ - c0_);
@@ -579,7 +605,20 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		for (int n = 0; n < R; ++n) if (n >= k) kstep (kc, ks, x[n]);
 		frames_left = (int) a.tile_frames - (R - k);
 	};
+	// the launch's last step where tiles are unaligned: the lanes of a last segment fetch their last_rows frames one by one
+	auto last_frames = [&]<int U> () __attribute__ ((always_inline)) {
+		const v2f* f = src + F0 + (int64_t) (n_steps - 1) * R;
+		int rows = lastq ? last_rows : R;                             // frames of the step that are this lane's to read
+		asm volatile ("" : "+v"(f), "+v"(rows));                      // (computed HERE, once: not sixteen addresses and masks kept across the main loop)
+		v2f t[R];
+#pragma unroll
+		for (int n = 0; n < R; ++n) t[n] = f[min (n, rows - 1)];
+#pragma unroll
+		for (int n = 0; n < R; ++n) xq[U][n] = n < rows ? t[n] : v2f{0.f, 0.f};
+		maxabs.template operator()<U> ();                             // (the maxima computed a step early saw a stale line)
+	};
 	auto do_step = [&]<int U, bool PROD> () __attribute__ ((always_inline)) {
+		if constexpr (!ALIGNED) if (cut && j == n_steps - 1) last_frames.template operator()<U> ();
 		if constexpr (!EBU || ALIGNED) step.template operator()<U, PROD, EBU> ();
 		else {
 			const bool boundary = frames_left <= R;                   // wave-uniform
@@ -643,7 +682,8 @@ int mtr_launch_seg (bool ebu, const mtr_seg_args& a, uint32_t n_waves, void* str
 {
 	hipStream_t st = (hipStream_t) stream;
 	const bool aligned = a.tile_frames % R == 0;
-	if (!ebu)         hipLaunchKernelGGL ((k_seg<false, false>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);    // (no tiles without Σ y²)
+	if (!ebu && aligned) hipLaunchKernelGGL ((k_seg<false, true>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);   // (no tiles without Σ y²; the
+	else if (!ebu)    hipLaunchKernelGGL ((k_seg<false, false>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);   // same code but for the launch's last step)
 	else if (aligned) hipLaunchKernelGGL ((k_seg<true, true>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);
 	else              hipLaunchKernelGGL ((k_seg<true, false>), dim3 (n_waves), dim3 (64), LDS_BYTES, st, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;

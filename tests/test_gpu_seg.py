@@ -69,7 +69,7 @@ def test_seg_matches_oracle(M, oracle, fs, segs):
     """Whole-fragment calls, calls with a tail behind the last fragment, several calls in a row (the K-filter state and
     the interpolator's history cross the call boundary), segments of unequal length (the shorter ones start a tile early).
     44.1 and 88.2 kHz: fragments of 2205 / 4410 frames are not whole 16-frame steps — a tile ends inside a step, segments
-    start on odd frames, and a call that is exactly N fragments long leaves its last fragment to the tail kernel."""
+    start on odd frames, and a stream's last segment stops inside the launch's last step (test_seg_unaligned_end_of_the_call)."""
     fragm = int(fs) // 20
     calls = [fragm * 37, fragm * 30 + 777, fragm * 3 - 777, fragm * 26]           # the 2nd call ends inside a fragment ...
     T = sum(calls)
@@ -78,8 +78,7 @@ def test_seg_matches_oracle(M, oracle, fs, segs):
     got = _run(M, x, calls, fs, tune_segments=segs, tune_layout=7)
     assert got["layout"] == 7
     # ... so the 3rd starts inside one: the rest of that fragment is the wave-per-segment kernel's, two whole fragments follow
-    whole = fragm % 16 == 0                                                        # (otherwise: 15 frames of read-ahead must exist behind the last tile)
-    assert got["seg"][0] == 4 and got["seg"][1] == fragm * (37 + 30 + 2 + 26 - (0 if whole else 3)), got["seg"]
+    assert got["seg"][0] == 4 and got["seg"][1] == fragm * (37 + 30 + 2 + 26), got["seg"]      # (every whole fragment, at every rate)
     for s in range(S):
         _check_ebu(got, oracle.ebu(x[s], fs, fragm, want_frag=True), s, (fs, segs))
         assert _rel(got["tp"][s], oracle.tp(x[s], fs, 8192)).max() <= TP_RTOL, (s, got["tp"][s])
@@ -96,7 +95,7 @@ def test_seg_not_taken_where_it_does_not_fit(M, oracle):
     T = 44100 * 4
     x = np.stack([tri_noise(T, 30 + s, 0.5, period=50000) for s in range(3)])
     got = _run(M, x, [T], 44100.0, tune_segments=4, tune_layout=7)
-    assert got["seg"] == (1, T - 2205), got["seg"]                              # the call is 80 fragments: the last one is the tail's
+    assert got["seg"] == (1, T), got["seg"]                                     # the call is 80 fragments: all of them, no tail launch
     for s in range(3):
         _check_ebu(got, oracle.ebu(x[s], 44100.0, 2205, want_frag=True), s, "44k1")
         assert _rel(got["tp"][s], oracle.tp(x[s], 44100.0, 8192)).max() <= TP_RTOL
@@ -353,3 +352,50 @@ def test_seg_is_deterministic_and_segmentation_independent(M):
     c = _run(M, x, [T], tune_segments=1, tune_layout=7)
     assert np.allclose(a["frag"], c["frag"], rtol=2e-6)                  # warm-up vs carried state: far below the 2e-5 gate
     assert _rel(a["tp"], c["tp"]).max() <= 1e-6                           # (the scale history of a lane differs)
+
+
+@pytest.mark.parametrize("fs", [44100.0, 88200.0])
+@pytest.mark.parametrize("tp_only", [False, True], ids=["ebu+tp", "tp"])
+def test_seg_unaligned_end_of_the_call(M, oracle, fs, tp_only):
+    """2205- / 4410-frame fragments: the call's last fragment ends 11 / 6 frames into the launch's last 16-frame step.  What
+    lies behind that frame is another stream's audio or nobody's: the lanes of a stream's last segment fetch the step frame
+    by frame and stop at the end (mtr_seg.hip).  Held here: (i) a peak in the call's last frames is found — the
+    interpolator's outputs up to the last frame count, phase 0 up to frame T - 25, as TruePeakdsp::process_max over the
+    same T frames has it; (ii) what follows a stream in memory does not reach its results: the streams lie back to back
+    (stride = T), every other one a filler that opens with 1e30 / Inf / NaN, the last stream followed by a guard of 1e30 —
+    bit for bit the results of the same streams between quiet fillers and in front of a zero guard; (iii) the oracle."""
+    import torch
+    fragm = int(fs) // 20
+    S, tiles = 7, 21
+    T = tiles * fragm
+    meters = M.METER_TRUEPEAK if tp_only else (M.METER_EBU | M.METER_TRUEPEAK)
+    x = np.stack([tri_noise(T, 4100 + s, 0.25, period=72000) for s in range(S)])
+    x[0, T - 2] = (0.9, -0.8)                                          # the interpolated peak of the call sits in its last frames
+    x[2, T - 30] = (-0.95, 0.7)                                        # ... phase 0 (|x[n - 24]|) still reaches this one
+    x[4, T - 9:T - 5] = 0.6
+    x[6, T - 1] = (0.99, 0.99)
+    hostile = x.copy()
+    for s, v in ((1, 1e30), (3, np.inf), (5, np.nan)):
+        hostile[s, :15] = v                                            # right behind the last frame of stream s - 1
+    st = torch.cuda.current_stream().cuda_stream
+    runs = {}
+    for name, data, guard in (("quiet", x, 0.0), ("hostile", hostile, 1e30)):
+        flat = torch.full((S * T * 2 + 64,), guard, dtype=torch.float32, device="cuda")
+        flat[:S * T * 2] = torch.from_numpy(data).cuda().reshape(-1)
+        with M.Engine(S, fs, meters, tune_segments=3, tune_layout=7) as e:
+            if not tp_only:
+                e.integr_start()
+            e.process_device(flat.data_ptr(), T, T, st)
+            torch.cuda.synchronize()
+            assert e.seg_stats() == (1, T), e.seg_stats()               # every fragment through k_seg: nothing left for a tail launch
+            runs[name] = (e.truepeak(), None if tp_only else e.out9(), None if tp_only else e.fragment_powers())
+    for s in (0, 2, 4, 6):
+        for a, b in zip(runs["quiet"], runs["hostile"]):
+            assert a is None or np.array_equal(a[s], b[s]), s
+        tp, o9, fr = (None if r is None else r[s] for r in runs["quiet"])
+        want = oracle.tp(x[s], fs, 8192)
+        assert _rel(tp, want).max() <= TP_RTOL, (s, tp, want)
+        if not tp_only:
+            ref = oracle.ebu(x[s], fs, fragm, want_frag=True)
+            assert np.allclose(fr, ref["frag_power"], rtol=2e-5), (s, np.abs(fr / ref["frag_power"] - 1).max())
+            assert abs(o9[4] - ref["out9"][4]) <= 0.01 and np.allclose(o9[:4], ref["out9"][:4], atol=1e-3), (s, o9, ref["out9"])

@@ -27,15 +27,16 @@ def test_headline_shape():
 
 
 @pytest.mark.parametrize("fs", [44100.0, 88200.0])
-def test_fragments_that_are_not_whole_steps_keep_their_read_ahead(fs):
+def test_fragments_that_are_not_whole_steps_all_go_to_the_batch_kernel(fs):
+    """2205 / 4410 frames are not whole 16-frame steps: the lanes of a stream's last segment stop at the frame their last
+    fragment ends on (mtr_seg.hip), so the launch needs no read-ahead behind the call and no fragment is left for a tail launch."""
     fragm = int(fs) // 20
     assert fragm % 16
-    p = q(8192, 200 * fragm, fs)                                    # exactly 200 fragments: the last one is the tail's
-    assert p["uses_seg"] == 1 and p["body_fragments"] == 199 and p["n_fragments_ended"] == 200
-    p = q(8192, 200 * fragm + 15, fs)
-    assert p["body_fragments"] == 199                               # 15 frames behind the body are one too few
-    p = q(8192, 200 * fragm + 16, fs)
-    assert p["body_fragments"] == 200
+    p = q(8192, 200 * fragm, fs)                                    # exactly 200 fragments
+    assert p["uses_seg"] == 1 and p["body_fragments"] == 200 and p["n_fragments_ended"] == 200 and p["n_tiles"] == 200
+    for extra in (1, 15, 16, fragm - 1):
+        p = q(8192, 200 * fragm + extra, fs)                        # what is left of the call is the tail kernel's, however little
+        assert p["body_fragments"] == 200 and p["n_tiles"] > 200 and p["frames_left_after"] == fragm - extra
     assert p["warm_steps"] % 4 == 0 and p["warm_steps"] * 16 >= 0.075 * fs
 
 
@@ -83,8 +84,7 @@ def test_plan_invariants_on_random_calls():
             head, body = p["head_frames"], p["body_fragments"]
             assert head == (0 if open_ == fragm else open_) and body >= 1
             assert head + body * fragm <= N
-            if fragm % 16:
-                assert head + body * fragm + 16 <= N                    # the last lane's read-ahead stays inside the call
+            assert body == (N - head) // fragm                          # every whole fragment, at every rate (no read-ahead behind the call)
             assert p["fragments_per_lane"] == math.ceil(body / p["segments"])
             if p["segments"] > 1:                                     # every later segment has its warm-up in front of it, inside the body
                 assert (body // p["segments"] - 1) * fragm >= p["warm_steps"] * 16
