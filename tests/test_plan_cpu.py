@@ -3,7 +3,7 @@ csrc/mtr_engine.hip), through mtr_plan_query: pure arithmetic, runs without a GP
 
 The reference has no counterpart (it walks its samples one by one, ebumeter/ebu_r128_proc.cc:217-244); what is held here
 is the contract the kernels rely on: tiles cover the call exactly, the lane = time segment kernel only ever gets whole
-fragments that it can read (15 frames of read-ahead at 44.1 / 88.2 kHz), segments are long enough for their warm-up."""
+fragments — all of them, at every rate (no read-ahead behind the call at 44.1 / 88.2 kHz) —, segments are long enough for their warm-up."""
 import math
 import random
 
