@@ -146,8 +146,20 @@ def self_launch(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     os.environ.setdefault("OMP_NUM_THREADS", "1")
+    # what the multi-rank tests set: this host's driver only supports dmabuf IPC, and without it RCCL's (and torch's)
+    # cross-process device-memory handles fail with "hipIpcGetMemHandle: invalid argument" — the job would then land on
+    # the gloo fallback, silently but for config.collective
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.stdout.flush()
     os.execv(sys.executable, cmd)
+
+
+def ctrl_timeout():
+    """Deadline of every collective of the control plane (gloo): a rank that is lost surfaces as an exception on the others
+    after this long — and rank 0 prints a line with an `error` field — well inside the driver's 1800 s, instead of after gloo's
+    default 30 minutes.  MTR_BENCH_CTRL_TIMEOUT_S overrides (default 300)."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("MTR_BENCH_CTRL_TIMEOUT_S", "300")))
 
 
 _REAL_STDOUT = None
@@ -179,7 +191,7 @@ def dry_run(args, rank, world):
     from meters.lv2_amd import dist as mdist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=ctrl_timeout())
     first, count = mdist.shard(args.streams * world, world, rank)
     mine = torch.tensor([rank, int(os.environ.get("LOCAL_RANK", "0")), first, count], dtype=torch.int64)
     rows = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
@@ -224,9 +236,40 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
-    if os.environ.get("MTR_BENCH_DRY_RUN") == "1":
-        return dry_run(args, rank, world)
+    done = []
 
+    def error_line(msg):
+        if rank == 0 and not done:
+            done.append(1)
+            emit({"metric": "audio samples/s (48 kHz stereo) EBU R128 + true-peak", "value": None, "unit": "samples/s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "error": msg})
+
+    if world > 1 and rank == 0:
+        # torch.distributed.run answers a rank that died with SIGTERM for the others: rank 0 still owes the driver its ONE line
+        import signal
+
+        def on_term(signum, frame):
+            error_line("terminated by the launcher (signal %d): a rank was lost" % signum)
+            os._exit(1)
+        signal.signal(signal.SIGTERM, on_term)
+    try:
+        fault = os.environ.get("MTR_BENCH_FAULT", "")            # tests only
+        if fault.startswith("hang_before_rendezvous:") and int(fault.split(":")[1]) == rank:
+            time.sleep(float(fault.split(":")[2]))
+            os._exit(3)
+        if os.environ.get("MTR_BENCH_DRY_RUN") == "1":
+            return dry_run(args, rank, world)
+        return run(args, rank, local, world)
+    except BaseException as exc:                                  # noqa: BLE001 — the driver gets ONE line whatever happened
+        if isinstance(exc, SystemExit) and not exc.code:
+            raise
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        error_line("%s: %s" % (type(exc).__name__, exc))
+        os._exit(1)                                               # (no destructor may wait for a rank that is gone)
+
+
+def run(args, rank, local, world):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -247,7 +290,7 @@ def main():
         # clock): gloo on 127.0.0.1.  The job's one RCCL communicator is the engine's own (mtr_comm_init, below) — no second
         # one is created beside it, so nothing can race its ncclCommInitRank on the same devices.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=ctrl_timeout())
 
     fs = args.fs
     S, T = args.streams, int(round(args.seconds * fs))
@@ -277,14 +320,26 @@ def main():
     # torch.distributed NCCL (= RCCL) group, then gloo on the same device buffers — what the shared-GPU rehearsal ends up with).
     torch.cuda.synchronize()
 
+    # The first contact with RCCL cannot hang the job: the communicator is built with a deadline (mtr_comm_init_timeout:
+    # ncclCommInitRankConfig non-blocking + ncclCommGetAsyncError polled), the first collective on it is probed with a
+    # deadline (mtr_comm_probe), and the ranks vote after each.  MTR_BENCH_COMM_TIMEOUT_S (default 120) is that deadline.
+    comm_timeout_s = float(os.environ.get("MTR_BENCH_COMM_TIMEOUT_S", "120"))
+    fault = os.environ.get("MTR_BENCH_FAULT", "")                # tests only: "sleep_in_init:<rank>:<seconds>"
+
     def make():
         if shared and os.environ.get("MTR_BENCH_TRY_RCCL") != "1":
             raise RuntimeError("not tried (MTR_BENCH_SHARED_GPU)")
-        return mdist.make_comm(rank, world, local)
+        if fault.startswith("sleep_in_init:"):
+            _, r, sec = fault.split(":")
+            if int(r) == rank:
+                time.sleep(float(sec))
+        return mdist.make_comm(rank, world, local, timeout_ms=int(1e3 * comm_timeout_s) if world > 1 else 0)
 
+    t_neg = time.perf_counter()
     comm, group, collective = mdist.agree_on_collective(
-        rank, world, make, device=dev, allow_nccl=not shared,
+        rank, world, make, device=dev, allow_nccl=not shared, probe_timeout_s=comm_timeout_s,
         log=lambda d: print("bench.py: rank %d: %s" % (rank, d), file=sys.stderr))
+    negotiation_ms = 1e3 * (time.perf_counter() - t_neg)
 
     def step():
         if mono:
@@ -353,7 +408,9 @@ def main():
                                    f"per-step RCCL all-reduce of 2x751 histograms + peaks",
                        "streams_per_gpu": S, "frames_per_stream": T, "sample_rate": fs,
                        "frames_per_s": frames_job / dt, "parallelism": f"streams sharded x{world}",
-                       "collective": collective},
+                       "collective": collective, "rccl_version": M.engine.rccl_version(),
+                       "comm_init_ms": getattr(comm, "init_ms", None), "comm_probe_ms": getattr(comm, "probe_ms", None),
+                       "comm_negotiation_ms": negotiation_ms, "comm_timeout_s": comm_timeout_s if world > 1 else None},
         }
         if world > 1:
             # What the ranks did on their own: every rank's loop before it waited for the others, and the GPU time of

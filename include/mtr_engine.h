@@ -34,6 +34,8 @@ extern "C" {
 #define MTR_ERR_NODEVICE    -3   /* no usable HIP device: the engine never falls back to the CPU */
 #define MTR_ERR_HIP         -4   /* a HIP runtime call failed; see mtr_last_error() */
 #define MTR_ERR_NOMEM       -5
+#define MTR_ERR_TIMEOUT     -6   /* a deadline passed (mtr_comm_init_timeout, mtr_comm_probe, mtr_engine_reduce on such a communicator) */
+#define MTR_ERR_STATE       -7   /* a state blob that does not fit this engine (mtr_engine_state_import) */
 
 /* ---- meters (bit mask) --------------------------------------------------- */
 #define MTR_METER_EBU        0x01u  /* Ebu_r128_proc: K-weighting + gated loudness  (ebumeter/ebu_r128_proc.cc) */
@@ -222,14 +224,48 @@ int  mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, 
 typedef struct mtr_comm mtr_comm;
 int  mtr_comm_unique_id (void* id128);
 int  mtr_comm_init (mtr_comm** out, int rank, int world, const void* id128, int device);
+/* The same with a DEADLINE, for a job's first contact with RCCL: ncclCommInitRankConfig (blocking = 0) and
+ * ncclCommGetAsyncError polled until the communicator stands, fails, or `timeout_ms` have passed — then ncclCommAbort and
+ * MTR_ERR_TIMEOUT, so that the host can fall back (a rank that never arrives would otherwise leave the others inside
+ * ncclCommInitRank for good).  timeout_ms = 0: mtr_comm_init (blocking, no deadline).  *init_ms (may be NULL): how long it took.
+ * Every later call on such a communicator is bounded the same way (mtr_comm_set_timeout; default: the init's deadline). */
+int  mtr_comm_init_timeout (mtr_comm** out, int rank, int world, const void* id128, int device, uint32_t timeout_ms, float* init_ms);
+/* One 4-byte all-reduce on the communicator's own stream, polled (hipStreamQuery + ncclCommGetAsyncError) to `timeout_ms`
+ * (0: wait for good): the job's first collective, before anything is timed.  MTR_ERR_TIMEOUT / MTR_ERR_HIP leave the
+ * communicator ABORTED: only mtr_comm_destroy may follow.  *ms (may be NULL): how long the collective took. */
+int  mtr_comm_probe (mtr_comm* c, uint32_t timeout_ms, float* ms);
+/* Deadline of the calls mtr_engine_reduce makes on a communicator built by mtr_comm_init_timeout (the enqueue of the
+ * collective, not its execution on the stream). */
+int  mtr_comm_set_timeout (mtr_comm* c, uint32_t timeout_ms);
 void mtr_comm_destroy (mtr_comm* c);
 int  mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max, void* hip_stream);
+/* ncclGetVersion of the RCCL this process runs (e.g. 22606), or a negative status. */
+int  mtr_rccl_version (void);
 
 /* Programme-level integrated loudness / range from (summed) histograms, exactly as
  * Ebu_r128_hist::calc_integ / calc_range do (ebu_r128_proc.cc:105-150). Host-side, pure C. */
 void mtr_hist_loudness (const int32_t* hist_M, const int32_t* hist_S,
                         float* integrated, float* integ_thr,
                         float* range_min, float* range_max, float* range_thr);
+
+/* ---- per-stream state: checkpoint / resume, re-sharding between engines ------------ */
+
+/* Everything streams [first, first + count) carry from call to call — K-filter states, the open fragment and the 64-fragment
+ * ring, both histograms and their counters, results and peak holds, the 47-frame interpolator history, ballistics, the
+ * bank's 30 x 12 section states, levels, peak holds and dither parity, the integer meters' tables, the DR-14 histograms and
+ * open window, the K-meter detector — as ONE opaque, versioned blob in host memory, together with the engine's lock-step
+ * cursors (frames left in the open fragment, integration on / off, samples in the open DR-14 window, the bank's speed).
+ * mtr_engine_state_import puts a blob's streams into slots [first, first + its count) of another engine of the SAME
+ * configuration (meters, channels, sample rate; n_streams and the slots may differ) — in another process, on another GPU —
+ * and processing continues bit for bit as if it had never stopped (tests/test_gpu_state.py).  An engine that has not
+ * processed anything since it was created or reset takes the blob's cursors; any other must stand at the same ones (the
+ * streams of an engine advance in lock step), else MTR_ERR_STATE.  Both calls synchronise.
+ * No reference counterpart: the reference persists one UI word (src/ebulv2.cc:514-553); SURVEY.md 5 (checkpoint / resume). */
+size_t mtr_engine_state_bytes (const mtr_engine* e, uint32_t count);
+int  mtr_engine_state_export (mtr_engine* e, uint32_t first, uint32_t count, void* blob, size_t capacity);
+int  mtr_engine_state_import (mtr_engine* e, uint32_t first, const void* blob, size_t bytes);
+/* Streams held by a blob (0 if it is not one). */
+uint32_t mtr_state_blob_count (const void* blob, size_t bytes);
 
 /* ---- measurement / introspection --------------------------------------------- */
 

@@ -8,11 +8,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mtr_internal.h"
@@ -91,6 +93,7 @@ struct mtr_engine {
 	uint32_t fragm = 0;           // frames per 50 ms fragment
 	uint32_t frcnt = 0;           // frames remaining in the open fragment (all streams in lock step)
 	bool     integr = false;
+	bool     advanced = false;    // a process call has run since create / reset: the lock-step cursors are no longer a fresh engine's
 	float    kw[7];
 	float    omega = 0.f;
 	hipStream_t last_stream = nullptr;
@@ -430,6 +433,7 @@ int mtr_engine_reset (mtr_engine* e)
 	}
 	e->frcnt = e->fragm;
 	e->integr = false;
+	e->advanced = false;
 	e->hist_cur = 0;
 	e->last_n_frag = 0;
 	if (e->cfg.meters & MTR_METER_DR14) { const int drc = mtr_engine_dr14_reset (e); if (drc) return drc; }
@@ -837,6 +841,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	e->last_stream = st;
 	e->queued = true;
 	e->snap_valid = false;
+	e->advanced = true;
 	const uint32_t S = e->v_cnt ? e->v_cnt : e->cfg.n_streams;     // the streams of this call's view ...
 	const size_t vo = e->v_cnt ? e->v_off : 0;                       // ... and where they start in every per-stream array
 	const bool ebu = e->cfg.meters & MTR_METER_EBU, tp = e->cfg.meters & MTR_METER_TRUEPEAK;
@@ -990,8 +995,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		e->hist_cur ^= 1;
 	}
 	if (tm) {
-		hipEvent_t v = next_event (e, ev0 + 3); if (v) HIPCHK (hipEventRecord (v, st));
-		e->timed_calls++;
+		hipEvent_t v = next_event (e, ev0 + 3);
+		if (v) { HIPCHK (hipEventRecord (v, st)); e->timed_calls++; }      // (a call without its four events is not a timed call)
 	}
 	return MTR_OK;
 }
@@ -1059,22 +1064,33 @@ int mtr_engine_process_host (mtr_engine* e, const float* h_audio, uint64_t n_fra
 	// the staging buffers may still be read by the previous call (on whatever stream that ran)
 	HIPCHK (hipStreamSynchronize (e->last_stream));
 	if (e->stage.reserve (buf_floats * (n_chunks > 1 ? 2 : 1))) return fail (MTR_ERR_NOMEM, "hipMalloc staging buffers");
+	// (every exit behind the first copy goes through ONE place that waits for the copy stream: the source is pageable caller
+	// memory and the copies are truly asynchronous — the caller may free or reuse it as soon as we return, error or not)
+	hipError_t he = hipSuccess;
+	const char* what = nullptr;
+#define HOSTCHK(call) do { he = (call); if (he != hipSuccess) { what = #call; goto done; } } while (0)
 	for (uint32_t k = 0, off = 0; k < n_chunks; ++k, off += cs) {
 		const uint32_t cnt = std::min (cs, S - off);
 		const int b = (int) (k & 1);
 		float* const dst = e->stage.p + (size_t) b * buf_floats;
-		if (k >= 2) HIPCHK (hipStreamWaitEvent (e->copy_stream, e->ev_computed[b], 0));   // the kernels of chunk k - 2 have read this buffer
-		HIPCHK (hipMemcpy2DAsync (dst, row * sizeof (float), h_audio + (size_t) off * stride * C, stride * C * sizeof (float),
-		                          n_frames * C * sizeof (float), cnt, hipMemcpyHostToDevice, e->copy_stream));
-		HIPCHK (hipEventRecord (e->ev_copied[b], e->copy_stream));
-		HIPCHK (hipStreamWaitEvent (st, e->ev_copied[b], 0));
+		if (k >= 2) HOSTCHK (hipStreamWaitEvent (e->copy_stream, e->ev_computed[b], 0));   // the kernels of chunk k - 2 have read this buffer
+		HOSTCHK (hipMemcpy2DAsync (dst, row * sizeof (float), h_audio + (size_t) off * stride * C, stride * C * sizeof (float),
+		                           n_frames * C * sizeof (float), cnt, hipMemcpyHostToDevice, e->copy_stream));
+		HOSTCHK (hipEventRecord (e->ev_copied[b], e->copy_stream));
+		HOSTCHK (hipStreamWaitEvent (st, e->ev_copied[b], 0));
 		rc = process_view (e, dst, n_frames, dstride, st, off, cnt, k + 1 == n_chunks);
-		if (rc) { (void) hipStreamSynchronize (e->copy_stream); return rc; }
-		HIPCHK (hipEventRecord (e->ev_computed[b], st));
+		if (rc) goto done;
+		HOSTCHK (hipEventRecord (e->ev_computed[b], st));
 	}
-	// The source is pageable caller memory and the copies are truly asynchronous: the caller may free or reuse it as soon
-	// as we return, so wait for the copies (not for the kernels) here.
-	HIPCHK (hipStreamSynchronize (e->copy_stream));
+#undef HOSTCHK
+done:
+	{
+		// wait for the copies (not for the kernels)
+		const hipError_t hs = hipStreamSynchronize (e->copy_stream);
+		if (what) return fail (MTR_ERR_HIP, what, he);
+		if (rc) return rc;
+		if (hs != hipSuccess) return fail (MTR_ERR_HIP, "hipStreamSynchronize (copy stream)", hs);
+	}
 	return MTR_OK;
 }
 
@@ -1252,6 +1268,10 @@ int mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, v
 struct mtr_comm {
 	ncclComm_t comm = nullptr;
 	int rank = 0, world = 1, device = 0;
+	bool nonblocking = false;          // built by mtr_comm_init_timeout: every call on it is polled to a deadline
+	uint32_t timeout_ms = 0;
+	hipStream_t probe_stream = nullptr;
+	int32_t* probe_buf = nullptr;
 };
 
 static int nccl_fail (const char* what, ncclResult_t r)
@@ -1260,6 +1280,46 @@ static int nccl_fail (const char* what, ncclResult_t r)
 	snprintf (buf, sizeof (buf), "%s: %s", what, ncclGetErrorString (r));
 	g_err = buf;
 	return MTR_ERR_HIP;
+}
+
+static double ms_since (std::chrono::steady_clock::time_point t0)
+{
+	return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t0).count ();
+}
+
+// the communicator is beyond repair (a deadline passed, an asynchronous error): abort it; only mtr_comm_destroy may follow
+static void comm_abort (mtr_comm* c)
+{
+	if (c->comm) (void) ncclCommAbort (c->comm);
+	c->comm = nullptr;
+}
+
+// A call on a non-blocking communicator returned ncclInProgress: poll its state until RCCL has taken the call in, it has
+// failed, or the deadline passes (then the communicator is aborted).  `t0` = when the call was made.
+static int comm_wait (mtr_comm* c, uint32_t timeout_ms, std::chrono::steady_clock::time_point t0, const char* what)
+{
+	for (;;) {
+		ncclResult_t state = ncclSuccess;
+		const ncclResult_t r = ncclCommGetAsyncError (c->comm, &state);
+		if (r != ncclSuccess) { comm_abort (c); return nccl_fail (what, r); }
+		if (state == ncclSuccess) return MTR_OK;
+		if (state != ncclInProgress) { comm_abort (c); return nccl_fail (what, state); }
+		if (timeout_ms && ms_since (t0) >= (double) timeout_ms) {
+			comm_abort (c);
+			char buf[160];
+			snprintf (buf, sizeof (buf), "%s: no answer from RCCL within %u ms (communicator aborted)", what, timeout_ms);
+			return fail (MTR_ERR_TIMEOUT, buf);
+		}
+		std::this_thread::sleep_for (std::chrono::microseconds (200));
+	}
+}
+
+int mtr_rccl_version (void)
+{
+	int v = 0;
+	const ncclResult_t r = ncclGetVersion (&v);
+	if (r != ncclSuccess) return nccl_fail ("ncclGetVersion", r);
+	return v;
 }
 
 int mtr_comm_unique_id (void* id128)
@@ -1273,10 +1333,11 @@ int mtr_comm_unique_id (void* id128)
 	return MTR_OK;
 }
 
-int mtr_comm_init (mtr_comm** out, int rank, int world, const void* id128, int device)
+int mtr_comm_init_timeout (mtr_comm** out, int rank, int world, const void* id128, int device, uint32_t timeout_ms, float* init_ms)
 {
 	if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return fail (MTR_ERR_ARG, "mtr_comm_init: bad argument");
 	*out = nullptr;
+	if (init_ms) *init_ms = 0.f;
 	int ndev = 0;
 	if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0) return fail (MTR_ERR_NODEVICE, "no HIP device");
 	if (device < 0 || device >= ndev) return fail (MTR_ERR_ARG, "device ordinal out of range");
@@ -1284,11 +1345,45 @@ int mtr_comm_init (mtr_comm** out, int rank, int world, const void* id128, int d
 	mtr_comm* c = new (std::nothrow) mtr_comm ();
 	if (!c) return fail (MTR_ERR_NOMEM, "new mtr_comm");
 	c->rank = rank; c->world = world; c->device = device;
+	c->nonblocking = timeout_ms != 0; c->timeout_ms = timeout_ms;
 	ncclUniqueId id;
 	memcpy (&id, id128, sizeof (id));
-	const ncclResult_t r = ncclCommInitRank (&c->comm, world, id, rank);
-	if (r != ncclSuccess) { delete c; return nccl_fail ("ncclCommInitRank", r); }
+	const auto t0 = std::chrono::steady_clock::now ();
+	int rc = MTR_OK;
+	if (!c->nonblocking) {
+		const ncclResult_t r = ncclCommInitRank (&c->comm, world, id, rank);
+		if (r != ncclSuccess) { c->comm = nullptr; rc = nccl_fail ("ncclCommInitRank", r); }
+	} else {
+		// the header may be newer than the RCCL this process runs (torch ships its own): never claim a newer version than the library's
+		ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+		int lib_version = 0;
+		if (ncclGetVersion (&lib_version) == ncclSuccess && lib_version > 0 && (unsigned) lib_version < cfg.version) cfg.version = (unsigned) lib_version;
+		cfg.blocking = 0;
+		const ncclResult_t r = ncclCommInitRankConfig (&c->comm, world, id, rank, &cfg);
+		if (r != ncclSuccess && r != ncclInProgress) { c->comm = nullptr; rc = nccl_fail ("ncclCommInitRankConfig", r); }
+		else if (!c->comm) rc = fail (MTR_ERR_HIP, "ncclCommInitRankConfig returned no communicator");
+		else rc = comm_wait (c, timeout_ms, t0, "ncclCommInitRankConfig");
+	}
+	if (rc == MTR_OK) {
+		if (hipStreamCreateWithFlags (&c->probe_stream, hipStreamNonBlocking) != hipSuccess || hipMalloc ((void**) &c->probe_buf, sizeof (int32_t)) != hipSuccess)
+			rc = fail (MTR_ERR_HIP, "mtr_comm_init: probe stream / buffer");
+	}
+	if (init_ms) *init_ms = (float) ms_since (t0);
+	if (rc != MTR_OK) { mtr_comm_destroy (c); return rc; }
 	*out = c;
+	return MTR_OK;
+}
+
+int mtr_comm_init (mtr_comm** out, int rank, int world, const void* id128, int device)
+{
+	return mtr_comm_init_timeout (out, rank, world, id128, device, 0, nullptr);
+}
+
+int mtr_comm_set_timeout (mtr_comm* c, uint32_t timeout_ms)
+{
+	if (!c) return fail (MTR_ERR_ARG, "mtr_comm_set_timeout: null communicator");
+	if (!c->nonblocking && timeout_ms) return fail (MTR_ERR_ARG, "mtr_comm_set_timeout: a communicator built by mtr_comm_init blocks; use mtr_comm_init_timeout");
+	c->timeout_ms = timeout_ms;
 	return MTR_OK;
 }
 
@@ -1296,26 +1391,197 @@ void mtr_comm_destroy (mtr_comm* c)
 {
 	if (!c) return;
 	(void) hipSetDevice (c->device);
-	if (c->comm) (void) ncclCommDestroy (c->comm);
+	if (c->comm) (void) (c->nonblocking ? ncclCommAbort (c->comm) : ncclCommDestroy (c->comm));   // (no second deadline at the exit: abort frees without a handshake)
+	if (c->probe_buf) (void) hipFree (c->probe_buf);
+	if (c->probe_stream) (void) hipStreamDestroy (c->probe_stream);
 	delete c;
+}
+
+int mtr_comm_probe (mtr_comm* c, uint32_t timeout_ms, float* ms)
+{
+	if (ms) *ms = 0.f;
+	if (!c) return fail (MTR_ERR_ARG, "mtr_comm_probe: null communicator");
+	if (!c->comm) return fail (MTR_ERR_ARG, "mtr_comm_probe: the communicator has been aborted");
+	HIPCHK (hipSetDevice (c->device));
+	const int32_t one = 1;
+	HIPCHK (hipMemcpyAsync (c->probe_buf, &one, sizeof (one), hipMemcpyHostToDevice, c->probe_stream));
+	HIPCHK (hipStreamSynchronize (c->probe_stream));
+	const auto t0 = std::chrono::steady_clock::now ();
+	const ncclResult_t r = ncclAllReduce (c->probe_buf, c->probe_buf, 1, ncclInt32, ncclSum, c->comm, c->probe_stream);
+	if (r != ncclSuccess && r != ncclInProgress) { comm_abort (c); return nccl_fail ("ncclAllReduce (probe)", r); }
+	if (c->nonblocking) { const int rc = comm_wait (c, timeout_ms, t0, "ncclAllReduce (probe)"); if (rc) return rc; }
+	// the collective itself: poll the stream, and the communicator for an asynchronous error (a peer that died)
+	for (;;) {
+		const hipError_t q = hipStreamQuery (c->probe_stream);
+		if (q == hipSuccess) break;
+		if (q != hipErrorNotReady) { comm_abort (c); return fail (MTR_ERR_HIP, "hipStreamQuery (probe)", q); }
+		ncclResult_t state = ncclSuccess;
+		if (ncclCommGetAsyncError (c->comm, &state) == ncclSuccess && state != ncclSuccess && state != ncclInProgress) { comm_abort (c); return nccl_fail ("ncclAllReduce (probe)", state); }
+		if (timeout_ms && ms_since (t0) >= (double) timeout_ms) {
+			comm_abort (c);
+			char buf[160];
+			snprintf (buf, sizeof (buf), "mtr_comm_probe: the first all-reduce did not finish within %u ms (communicator aborted)", timeout_ms);
+			return fail (MTR_ERR_TIMEOUT, buf);
+		}
+		std::this_thread::sleep_for (std::chrono::microseconds (100));
+	}
+	if (ms) *ms = (float) ms_since (t0);
+	int32_t got = 0;
+	HIPCHK (hipMemcpy (&got, c->probe_buf, sizeof (got), hipMemcpyDeviceToHost));
+	if (got != c->world) {
+		char buf[160];
+		snprintf (buf, sizeof (buf), "mtr_comm_probe: all-reduce of ones over %d ranks gave %d", c->world, (int) got);
+		comm_abort (c);
+		return fail (MTR_ERR_HIP, buf);
+	}
+	return MTR_OK;
 }
 
 int mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max, void* hip_stream)
 {
 	if (!e || !c || !d_hist || !d_max) return fail (MTR_ERR_ARG, "mtr_engine_reduce: null argument");
+	if (!c->comm) return fail (MTR_ERR_ARG, "mtr_engine_reduce: the communicator has been aborted");
 	if (c->device != e->cfg.device) return fail (MTR_ERR_ARG, "mtr_engine_reduce: engine and communicator sit on different devices");
 	int rc = mtr_engine_aggregate_device (e, d_hist, d_max, hip_stream);
 	if (rc) return rc;
 	hipStream_t st = (hipStream_t) hip_stream;
 	// one group: RCCL launches the sum and the max together (6 KB + 16 B: both are pure latency on xGMI)
+	const auto t0 = std::chrono::steady_clock::now ();
 	ncclResult_t r = ncclGroupStart ();
 	if (r != ncclSuccess) return nccl_fail ("ncclGroupStart", r);
 	const ncclResult_t r1 = ncclAllReduce (d_hist, d_hist, 2 * MTR_HIST_LEN, ncclInt32, ncclSum, c->comm, st);
 	const ncclResult_t r2 = ncclAllReduce (d_max, d_max, 4, ncclFloat32, ncclMax, c->comm, st);
 	r = ncclGroupEnd ();
-	if (r1 != ncclSuccess) return nccl_fail ("ncclAllReduce (histograms)", r1);
-	if (r2 != ncclSuccess) return nccl_fail ("ncclAllReduce (peaks)", r2);
+	if (r1 != ncclSuccess && r1 != ncclInProgress) return nccl_fail ("ncclAllReduce (histograms)", r1);
+	if (r2 != ncclSuccess && r2 != ncclInProgress) return nccl_fail ("ncclAllReduce (peaks)", r2);
+	if (r == ncclInProgress && c->nonblocking) return comm_wait (c, c->timeout_ms, t0, "ncclGroupEnd (mtr_engine_reduce)");
 	if (r != ncclSuccess) return nccl_fail ("ncclGroupEnd", r);
+	return MTR_OK;
+}
+
+// ---- per-stream state: checkpoint / resume, re-sharding ----------------------------------------------------------------
+} // extern "C"
+namespace {
+
+struct StateHeader {
+	uint32_t magic, version, header_bytes;
+	uint32_t meters, n_channels;
+	float    sample_rate;
+	uint32_t count, per_stream_bytes, stream_state_bytes;
+	// the engine's lock-step cursors
+	uint32_t frcnt, integr;
+	float    omega;
+	uint64_t dr_scnt;
+};
+constexpr uint32_t STATE_MAGIC = 0x5352544du;   // "MTRS"
+constexpr uint32_t STATE_VERSION = 1;
+
+struct StateSection { const void* base; size_t elem; };   // a per-stream array: `elem` bytes per stream
+
+// every array a stream carries from call to call, in the blob's order (a function of the configuration alone)
+std::vector<StateSection> state_sections (const mtr_engine* e)
+{
+	std::vector<StateSection> v;
+	const uint32_t m = e->cfg.meters;
+	v.push_back ({ e->state.p, sizeof (mtr_stream_state) });
+	v.push_back ({ e->hist.p, (size_t) 2 * MTR_HIST_LEN * sizeof (int32_t) });
+	v.push_back ({ e->fir_hist[e->hist_cur].p, (size_t) MTR_FIR_HALO * 2 * sizeof (float) });
+	if (m & MTR_METER_SPECTR30) {
+		v.push_back ({ e->bank_z.p, (size_t) MTR_NBANDS * 12 * sizeof (double) });
+		v.push_back ({ e->bank_val.p, (size_t) MTR_NBANDS * sizeof (float) });
+		v.push_back ({ e->bank_max.p, (size_t) MTR_NBANDS * sizeof (float) });
+		v.push_back ({ e->bank_ac[e->bank_ac_cur].p, sizeof (int32_t) });
+	}
+	if (m & MTR_METER_BITSTATS) v.push_back ({ e->bim.p, sizeof (mtr_bitstats_state) });
+	if (m & MTR_METER_SIGDIST) v.push_back ({ e->sdh.p, sizeof (mtr_sigdist_state) });
+	if (m & MTR_METER_DR14) {
+		v.push_back ({ e->dr_state.p, sizeof (mtr_dr14_state) });
+		v.push_back ({ e->dr_hist.p, (size_t) e->cfg.n_channels * MTR_DR_HISTBINS * sizeof (uint32_t) });
+	}
+	if (m & MTR_METER_KMETER) v.push_back ({ e->km_state.p, 2 * sizeof (mtr_kmeter_state) });
+	return v;
+}
+
+size_t state_per_stream (const mtr_engine* e)
+{
+	size_t n = 0;
+	for (const StateSection& s : state_sections (e)) n += s.elem;
+	return n;
+}
+
+}  // namespace
+extern "C" {
+
+size_t mtr_engine_state_bytes (const mtr_engine* e, uint32_t count)
+{
+	if (!e) return 0;
+	return sizeof (StateHeader) + (size_t) count * state_per_stream (e);
+}
+
+uint32_t mtr_state_blob_count (const void* blob, size_t bytes)
+{
+	StateHeader h;
+	if (!blob || bytes < sizeof (h)) return 0;
+	memcpy (&h, blob, sizeof (h));
+	if (h.magic != STATE_MAGIC || h.version != STATE_VERSION || h.header_bytes != sizeof (h)) return 0;
+	if (bytes < sizeof (h) + (size_t) h.count * h.per_stream_bytes) return 0;
+	return h.count;
+}
+
+int mtr_engine_state_export (mtr_engine* e, uint32_t first, uint32_t count, void* blob, size_t capacity)
+{
+	int rc = check_range (e, first, count);
+	if (rc) return rc;
+	if (!blob) return fail (MTR_ERR_ARG, "mtr_engine_state_export: null blob");
+	const size_t need = mtr_engine_state_bytes (e, count);
+	if (capacity < need) return fail (MTR_ERR_ARG, "mtr_engine_state_export: capacity < mtr_engine_state_bytes ()");
+	rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	StateHeader h;
+	memset (&h, 0, sizeof (h));
+	h.magic = STATE_MAGIC; h.version = STATE_VERSION; h.header_bytes = sizeof (h);
+	h.meters = e->cfg.meters; h.n_channels = e->cfg.n_channels; h.sample_rate = e->cfg.sample_rate;
+	h.count = count; h.per_stream_bytes = (uint32_t) state_per_stream (e); h.stream_state_bytes = sizeof (mtr_stream_state);
+	h.frcnt = e->frcnt; h.integr = e->integr ? 1u : 0u; h.omega = e->omega; h.dr_scnt = e->dr_scnt;
+	memcpy (blob, &h, sizeof (h));
+	unsigned char* o = static_cast<unsigned char*> (blob) + sizeof (h);
+	for (const StateSection& s : state_sections (e)) {
+		if (count) HIPCHK (hipMemcpy (o, static_cast<const unsigned char*> (s.base) + (size_t) first * s.elem, (size_t) count * s.elem, hipMemcpyDeviceToHost));
+		o += (size_t) count * s.elem;
+	}
+	return MTR_OK;
+}
+
+int mtr_engine_state_import (mtr_engine* e, uint32_t first, const void* blob, size_t bytes)
+{
+	if (!e || !blob) return fail (MTR_ERR_ARG, "mtr_engine_state_import: null argument");
+	StateHeader h;
+	if (bytes < sizeof (h)) return fail (MTR_ERR_STATE, "mtr_engine_state_import: not a state blob (too short)");
+	memcpy (&h, blob, sizeof (h));
+	if (h.magic != STATE_MAGIC) return fail (MTR_ERR_STATE, "mtr_engine_state_import: not a state blob (magic)");
+	if (h.version != STATE_VERSION || h.header_bytes != sizeof (h)) return fail (MTR_ERR_STATE, "mtr_engine_state_import: blob of another format version");
+	if (h.meters != e->cfg.meters || h.n_channels != e->cfg.n_channels || h.sample_rate != e->cfg.sample_rate)
+		return fail (MTR_ERR_STATE, "mtr_engine_state_import: the blob comes from another configuration (meters, channels or sample rate)");
+	if (h.stream_state_bytes != sizeof (mtr_stream_state) || h.per_stream_bytes != state_per_stream (e))
+		return fail (MTR_ERR_STATE, "mtr_engine_state_import: the blob's per-stream layout is not this build's");
+	if (bytes < sizeof (h) + (size_t) h.count * h.per_stream_bytes) return fail (MTR_ERR_STATE, "mtr_engine_state_import: truncated blob");
+	int rc = check_range (e, first, h.count);
+	if (rc) return rc;
+	// the streams of an engine advance in lock step: a fresh engine takes the blob's cursors, any other must stand at the same ones
+	if (!e->advanced) {
+		e->frcnt = h.frcnt; e->integr = h.integr != 0; e->omega = h.omega; e->dr_scnt = h.dr_scnt;
+		e->plan.valid = false;
+		e->advanced = true;
+	} else if (e->frcnt != h.frcnt || e->integr != (h.integr != 0) || e->omega != h.omega || e->dr_scnt != h.dr_scnt)
+		return fail (MTR_ERR_STATE, "mtr_engine_state_import: the engine does not stand where the blob's streams do (fragment phase, integration, bank speed or DR-14 window)");
+	rc = mtr_engine_sync (e);
+	if (rc) return rc;
+	e->snap_valid = false;
+	const unsigned char* i = static_cast<const unsigned char*> (blob) + sizeof (h);
+	for (const StateSection& s : state_sections (e)) {
+		if (h.count) HIPCHK (hipMemcpy (const_cast<unsigned char*> (static_cast<const unsigned char*> (s.base)) + (size_t) first * s.elem, i, (size_t) h.count * s.elem, hipMemcpyHostToDevice));
+		i += (size_t) h.count * s.elem;
+	}
 	return MTR_OK;
 }
 
@@ -1401,7 +1667,7 @@ int mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, flo
 	int rc = mtr_engine_sync (e);
 	if (rc) return rc;
 	float f = 0, g = 0, b = 0;
-	for (uint32_t i = 0; i < e->timed_calls; ++i) {
+	for (uint32_t i = 0; i < e->timed_calls && (size_t) i * 4 + 3 < e->ev.size (); ++i) {
 		float t;
 		if (hipEventElapsedTime (&t, e->ev[i * 4], e->ev[i * 4 + 1]) == hipSuccess) f += t;
 		if (hipEventElapsedTime (&t, e->ev[i * 4 + 1], e->ev[i * 4 + 2]) == hipSuccess) g += t;
@@ -1421,7 +1687,7 @@ int mtr_engine_timing_calls (mtr_engine* e, float* out, uint32_t cap, uint32_t* 
 	int rc = mtr_engine_sync (e);
 	if (rc) return rc;
 	if (calls) *calls = e->timed_calls;
-	for (uint32_t i = 0; i < e->timed_calls && i < cap; ++i) {
+	for (uint32_t i = 0; i < e->timed_calls && i < cap && (size_t) i * 4 + 3 < e->ev.size (); ++i) {
 		float* o = out + (size_t) i * 4;
 		for (int k = 0; k < 3; ++k)
 			if (hipEventElapsedTime (&o[k], e->ev[i * 4 + k], e->ev[i * 4 + k + 1]) != hipSuccess) o[k] = 0.f;

@@ -30,25 +30,31 @@ def all_reduce_aggregate(hist, maxv, group=None):
     return hist, maxv
 
 
-def make_comm(rank, world, device=0):
-    """One engine communicator per rank: rank 0 draws the RCCL id, torch.distributed (any backend) ships it."""
+def make_comm(rank, world, device=0, timeout_ms=0):
+    """One engine communicator per rank: rank 0 draws the RCCL id, torch.distributed (any backend) ships it.
+    timeout_ms > 0: mtr_comm_init_timeout — a rank that never arrives costs the others that long, not forever."""
     import torch.distributed as dist
     uid = [_engine.comm_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
-    return _engine.Comm(rank, world, uid[0], device)
+    return _engine.Comm(rank, world, uid[0], device, timeout_ms=timeout_ms)
 
 
-def agree_on_collective(rank, world, make, device=None, allow_nccl=True, log=None):
+def agree_on_collective(rank, world, make, device=None, allow_nccl=True, log=None, probe_timeout_s=60.0):
     """How the ranks of a job reduce — decided TOGETHER, so that no rank ever sits alone inside a collective.
 
-    `make()` builds this rank's engine communicator (mtr_comm_init behind it: itself a collective call) or raises.  Every
-    rank is here before anyone starts (a barrier on both sides); then the ranks vote (MIN over "mine succeeded", on CPU
-    tensors: the process group is the control plane, gloo).  All succeeded -> (comm, None, "RCCL behind the C ABI ...").
-    Otherwise every rank closes what it built and the ranks fall back, in order: a torch.distributed NCCL (= RCCL) group,
-    probed with one all-reduce on `device` and voted on the same way (skipped where allow_nccl is False: two ranks on one
-    GPU, or no GPU at all), then the default group — gloo, device buffers through the host.  Returns (comm, group,
-    description); the description names the fallback and why."""
+    `make()` builds this rank's engine communicator (mtr_comm_init_timeout behind it: itself a collective call, bounded by
+    its deadline) or raises.  Every rank is here before anyone starts (a barrier on both sides); then the ranks vote (MIN
+    over "mine succeeded", on CPU tensors: the process group is the control plane, gloo).  All succeeded -> the job's FIRST
+    collective is probed the same way (`comm.probe`: one 4-byte all-reduce polled to `probe_timeout_s`, then a vote) ->
+    (comm, None, "RCCL behind the C ABI ...").  Otherwise every rank closes what it built and the ranks fall back, in
+    order: a torch.distributed NCCL (= RCCL) group — voted on right after it is created, before any traffic on it, then
+    probed with one ASYNCHRONOUS all-reduce on `device` that is waited for `probe_timeout_s` at most and voted on again
+    (skipped where allow_nccl is False: two ranks on one GPU, or no GPU at all) — then the default group: gloo, device
+    buffers through the host.  Returns (comm, group, description); the description names the fallback and why.
+    A rank that is lost altogether surfaces as the control plane's own timeout (init_process_group(timeout=...))."""
+    import time
+
     import torch
     import torch.distributed as dist
 
@@ -70,22 +76,47 @@ def agree_on_collective(rank, world, make, device=None, allow_nccl=True, log=Non
         if err:
             raise err
         return comm, None, "RCCL behind the C ABI (mtr_engine_reduce)"
+    why = None
     if agreed(err is None):
-        dist.barrier()
-        return comm, None, "RCCL behind the C ABI (mtr_engine_reduce)"
+        # every rank holds a communicator: the first collective on it, bounded, before anything is timed
+        try:
+            if hasattr(comm, "probe"):
+                comm.probe_ms = comm.probe(int(1e3 * probe_timeout_s))
+        except Exception as ex:                                   # noqa: BLE001
+            err = ex
+        if agreed(err is None):
+            dist.barrier()
+            return comm, None, "RCCL behind the C ABI (mtr_engine_reduce)"
+        why = "the first all-reduce on the engine's communicator failed on a rank: %s" % (err or "another rank")
+    else:
+        why = "mtr_comm_init failed on a rank: %s" % (err or "another rank")
     if comm is not None:
         comm.close()
-    why = "mtr_comm_init failed on a rank: %s" % (err or "another rank")
     group, ok = None, False
     if allow_nccl:
         try:
             group = dist.new_group(backend="nccl")               # "nccl" is RCCL on ROCm
-            probe = torch.ones(1, dtype=torch.int32, device=device)
-            dist.all_reduce(probe, group=group)
-            ok = int(probe.item()) == world
+            ok = True
         except Exception as ex:                                   # noqa: BLE001
             why += "; torch NCCL group: %r" % (ex,)
-        ok = agreed(ok)
+        if agreed(ok):                                            # nobody touches the group unless everybody has one
+            ok = False
+            try:
+                probe = torch.ones(1, dtype=torch.int32, device=device)
+                work = dist.all_reduce(probe, group=group, async_op=True)
+                t_end = time.monotonic() + probe_timeout_s
+                while not work.is_completed() and time.monotonic() < t_end:
+                    time.sleep(0.01)
+                if work.is_completed():
+                    work.wait()
+                    ok = int(probe.item()) == world
+                else:
+                    why += "; torch NCCL group: the probe all-reduce did not finish within %g s" % probe_timeout_s
+            except Exception as ex:                               # noqa: BLE001
+                why += "; torch NCCL group: %r" % (ex,)
+            ok = agreed(ok)
+        else:
+            ok = False
     if ok:
         desc = "torch.distributed all_reduce over a NCCL (= RCCL) group (%s)" % why
     else:

@@ -22,7 +22,11 @@ lib_path = os.environ.get("MTR_LIB") or os.path.join(_HERE, "lib", "libmtr_engin
 
 
 class EngineError(RuntimeError):
-    pass
+    """A C-ABI call returned a status other than MTR_OK; `.code` is that status (ERR_TIMEOUT, ERR_STATE, ...)."""
+    code = 0
+
+
+ERR_ARG, ERR_UNSUPPORTED, ERR_NODEVICE, ERR_HIP, ERR_NOMEM, ERR_TIMEOUT, ERR_STATE = -1, -2, -3, -4, -5, -6, -7
 
 
 class _Config(C.Structure):
@@ -118,6 +122,16 @@ def _load():
     L.mtr_plan_query.argtypes = [vp, u32, u64, u32, vp]
     L.mtr_comm_unique_id.argtypes = [vp]
     L.mtr_comm_init.argtypes = [C.POINTER(vp), i32, i32, vp, i32]
+    L.mtr_comm_init_timeout.argtypes = [C.POINTER(vp), i32, i32, vp, i32, u32, C.POINTER(f32)]
+    L.mtr_comm_probe.argtypes = [vp, u32, C.POINTER(f32)]
+    L.mtr_comm_set_timeout.argtypes = [vp, u32]
+    L.mtr_rccl_version.argtypes = []
+    L.mtr_engine_state_bytes.argtypes = [vp, u32]
+    L.mtr_engine_state_bytes.restype = C.c_size_t
+    L.mtr_engine_state_export.argtypes = [vp, u32, u32, vp, C.c_size_t]
+    L.mtr_engine_state_import.argtypes = [vp, u32, vp, C.c_size_t]
+    L.mtr_state_blob_count.argtypes = [vp, C.c_size_t]
+    L.mtr_state_blob_count.restype = u32
     L.mtr_comm_destroy.argtypes = [vp]
     L.mtr_comm_destroy.restype = None
     L.mtr_engine_reduce.argtypes = [vp, vp, vp, vp, vp]
@@ -138,7 +152,9 @@ lib = _load()
 
 def _check(rc, what):
     if rc != 0:
-        raise EngineError(f"{what} failed ({rc}): {lib.mtr_last_error().decode()}")
+        err = EngineError(f"{what} failed ({rc}): {lib.mtr_last_error().decode()}")
+        err.code = rc
+        raise err
 
 
 def exported_symbols():
@@ -201,13 +217,35 @@ def comm_unique_id():
     return bytes(buf.raw)
 
 
-class Comm:
-    """mtr_comm: one RCCL communicator per rank (ncclCommInitRank is collective: every rank constructs its own)."""
+def rccl_version():
+    """ncclGetVersion of the RCCL this process runs, e.g. 22606."""
+    v = lib.mtr_rccl_version()
+    if v < 0:
+        _check(v, "rccl_version")
+    return v
 
-    def __init__(self, rank, world, unique_id, device=0):
+
+class Comm:
+    """mtr_comm: one RCCL communicator per rank (ncclCommInitRank is collective: every rank constructs its own).
+    timeout_ms > 0: mtr_comm_init_timeout — the creation (and every later call on the communicator) is polled to that
+    deadline and raises EngineError with code ERR_TIMEOUT instead of hanging; `.init_ms` is how long the creation took."""
+
+    def __init__(self, rank, world, unique_id, device=0, timeout_ms=0):
         self._h = C.c_void_p()
+        self.world = world
         buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
-        _check(lib.mtr_comm_init(C.byref(self._h), rank, world, buf, device), "comm_init")
+        ms = C.c_float()
+        _check(lib.mtr_comm_init_timeout(C.byref(self._h), rank, world, buf, device, int(timeout_ms), C.byref(ms)), "comm_init")
+        self.init_ms = ms.value
+
+    def probe(self, timeout_ms=0):
+        """The job's first collective (one 4-byte all-reduce on the communicator's own stream), bounded; returns its ms."""
+        ms = C.c_float()
+        _check(lib.mtr_comm_probe(self._h, int(timeout_ms), C.byref(ms)), "comm_probe")
+        return ms.value
+
+    def set_timeout(self, timeout_ms):
+        _check(lib.mtr_comm_set_timeout(self._h, int(timeout_ms)), "comm_set_timeout")
 
     def close(self):
         if self._h:
@@ -365,6 +403,22 @@ class Engine:
 
     def intstat_reset(self):
         _check(lib.mtr_engine_intstat_reset(self._h), "intstat_reset")
+
+    def state_bytes(self, count):
+        return int(lib.mtr_engine_state_bytes(self._h, count))
+
+    def state_export(self, first=0, count=None):
+        """Everything streams [first, first + count) carry from call to call, as one opaque blob (bytes)."""
+        count = self.n_streams - first if count is None else count
+        buf = C.create_string_buffer(self.state_bytes(count))
+        _check(lib.mtr_engine_state_export(self._h, first, count, buf, len(buf)), "state_export")
+        return bytes(buf.raw)
+
+    def state_import(self, blob, first=0):
+        """Put a blob's streams into slots [first, first + its count) of this engine (same meters / channels / rate)."""
+        blob = bytes(blob)
+        _check(lib.mtr_engine_state_import(self._h, first, blob, len(blob)), "state_import")
+        return int(lib.mtr_state_blob_count(blob, len(blob)))
 
     def aggregate_device(self, hist_ptr, max_ptr, stream=0):
         _check(lib.mtr_engine_aggregate_device(self._h, hist_ptr, max_ptr, stream), "aggregate_device")

@@ -97,5 +97,59 @@ def main():
     print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")
 
 
+def tpb_cases():
+    """(name, fs, block, mono float32 input): the ballistics cases of golden_v2 — exactly reproducible inputs (LCG noise, power-of-two
+    and decimal-literal gains applied in float32)."""
+    out = []
+    for fs in (44100.0, 96000.0):
+        x = (sig.lcg_noise(int(fs) * 2, 9 + int(fs) % 97)[:, 0] * np.float32(0.5)).copy()
+        out.append(("tpb_%d" % int(fs), fs, 1024, x))
+    # levels the +-0.01 dB contract must hold at: -40 / -60 / -80 dBFS (VERDICT r4 item 3)
+    for db, g in ((40, 1e-2), (60, 1e-3), (80, 1e-4)):
+        x = (sig.lcg_noise(48000, 21 + db)[:, 0] * np.float32(g)).astype(np.float32)
+        out.append(("tpb_m%ddbfs" % db, 48000.0, 8192, x))
+    return out
+
+
+NAN_AT, NAN_T = 2000, 2600
+
+
+def nan_cases():
+    """Three mono signals with ONE NaN at frame NAN_AT in quiet noise (2^-12), 2600 frames.  What the reference's `if (v > m)` loses is
+    decided by the 48-tap windows that contain the NaN — output frames NAN_AT .. NAN_AT + 47, all four phases (0 x NaN = NaN) — and
+    by nothing else:
+      A  full-scale finite samples 30, 50 and 63 frames on either side of the NaN (VERDICT r4 item 3): all of them stay visible;
+      B  an fs/4 burst (+3.1 dB between the samples) whose interpolated peaks fall into the 16 output frames BEHIND the NaN's windows;
+      C  a 0.9 sample ten frames in front of the NaN: its own output frame (+ 24) lies inside the NaN's windows, the reference loses it."""
+    base = (sig.lcg_noise(NAN_T, 5)[:, 0] * np.float32(2.0 ** -12)).copy()
+    a, b, c = base.copy(), base.copy(), base.copy()
+    for x in (a, b, c):
+        x[NAN_AT] = np.nan
+    for d, v in ((30, 1.0), (50, -0.875), (63, 0.75)):
+        a[NAN_AT - d] = np.float32(v)
+        a[NAN_AT + d] = np.float32(-v * 0.9375)
+    b[NAN_AT + 26:NAN_AT + 42] = np.tile(np.array([0.5, 0.5, -0.5, -0.5], np.float32), 4)
+    c[NAN_AT - 10] = np.float32(0.9)
+    return {"A": a, "B": b, "C": c}
+
+
+def main_v2():
+    """tests/golden/golden_v2.npz: TruePeakdsp::process at 44.1 and 96 kHz and at low levels, process_max around a NaN (round 5)."""
+    build_ref()
+    ref = Reference()
+    g = {}
+    for name, fs, block, x in tpb_cases():
+        g[name] = ref.tp_process_seq(x, fs, block)
+    for k, x in nan_cases().items():
+        g["tp_nan_%s_out" % k] = ref.tp_resample(x)                     # the 4x stream itself, NaNs where the reference has them
+        g["tp_nan_%s_peak" % k] = ref.tp(np.stack([x, x], 1), 48000.0, 1024)
+    out = os.path.join(HERE, "golden_v2.npz")
+    np.savez_compressed(out, **g)
+    print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "v2":
+        main_v2()
+    else:
+        main()

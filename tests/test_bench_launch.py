@@ -41,3 +41,20 @@ def test_rank_count_mismatch_is_an_error():
     e = dict(os.environ, MTR_BENCH_DRY_RUN="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "--gpus 4" in r.stderr
+
+
+def test_a_rank_that_never_arrives_yields_one_line_with_an_error():
+    """the control plane has a deadline (MTR_BENCH_CTRL_TIMEOUT_S; gloo's default is 30 minutes) — a rank
+    that hangs before the rendezvous costs the job that long, and rank 0 still prints exactly one JSON line, with `error`."""
+    e = dict(os.environ, MTR_BENCH_DRY_RUN="1", MTR_BENCH_CTRL_TIMEOUT_S="5", MTR_BENCH_FAULT="hang_before_rendezvous:1:40")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--streams", "9"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=240)
+    took = time.monotonic() - t0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["error"]
+    assert took < 120, took

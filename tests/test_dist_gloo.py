@@ -76,6 +76,13 @@ def test_two_rank_reduce_equals_single_process(tmp_path):
 
 class _FakeComm:
     closed = 0
+    probed = 0
+    probe_fails = False
+
+    def probe(self, timeout_ms=0):
+        _FakeComm.probed += 1
+        if self.probe_fails:
+            raise RuntimeError("mtr_comm_probe: the first all-reduce did not finish within %d ms" % timeout_ms)
 
     def close(self):
         _FakeComm.closed += 1
@@ -90,20 +97,31 @@ def _agree_worker(rank, world, port, scenario, out):
     def make():
         if scenario == "one-fails" and rank == 1 or scenario == "all-fail":
             raise RuntimeError("ncclCommInitRank: refused (rank %d)" % rank)
-        return _FakeComm()
+        if scenario == "one-sleeps":
+            # rank 1 sleeps through the others' deadline; mtr_comm_init_timeout gives rank 0 up after its own (here: 0.5 s),
+            # and rank 1, arriving late, finds nobody and times out as well
+            import time
+            time.sleep(4.0 if rank == 1 else 0.5)
+            raise RuntimeError("ncclCommInitRankConfig: no answer from RCCL within 500 ms (communicator aborted)")
+        c = _FakeComm()
+        c.probe_fails = scenario == "probe-fails" and rank == 1
+        return c
 
-    comm, group, desc = mdist.agree_on_collective(rank, world, make, allow_nccl=False)
+    import time
+    t0 = time.monotonic()
+    comm, group, desc = mdist.agree_on_collective(rank, world, make, allow_nccl=False, probe_timeout_s=2.0)
+    took = time.monotonic() - t0
     # whatever was agreed, the ranks reduce the same way: a collective on the default group must still work
     t = torch.tensor([rank + 1], dtype=torch.int32)
     mdist.all_reduce_aggregate(t, torch.zeros(1), group)
-    torch.save(dict(comm=comm is not None, group=group is not None, desc=desc, closed=_FakeComm.closed, sum=int(t.item())),
-               out + ".%d" % rank)
+    torch.save(dict(comm=comm is not None, group=group is not None, desc=desc, closed=_FakeComm.closed, sum=int(t.item()),
+                    probed=_FakeComm.probed, took=took), out + ".%d" % rank)
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("scenario", ["all-succeed", "one-fails", "all-fail"])
+@pytest.mark.parametrize("scenario", ["all-succeed", "one-fails", "all-fail", "one-sleeps", "probe-fails"])
 def test_ranks_agree_on_how_they_reduce(tmp_path, scenario):
     """bench.py's negotiation at N > 1 (meters.lv2_amd.dist.agree_on_collective), on two gloo ranks without a GPU: the
     engine communicator is kept only if EVERY rank built one; a rank whose mtr_comm_init succeeded while another's failed
@@ -116,6 +134,18 @@ def test_ranks_agree_on_how_they_reduce(tmp_path, scenario):
     if scenario == "all-succeed":
         assert all(x["comm"] and not x["group"] and "RCCL behind the C ABI" in x["desc"] for x in r)
         assert r[0]["closed"] == r[1]["closed"] == 0
+        assert r[0]["probed"] == r[1]["probed"] == 1           # the job's first collective ran before anything else
+    elif scenario == "one-sleeps":
+        # a rank that sleeps through the communicator's creation: the others time out (mtr_comm_init_timeout), every rank
+        # votes, and the job goes on over the fallback — in the sleeper's time, not the control plane's 30 minutes
+        assert not any(x["comm"] or x["group"] for x in r)
+        assert all("gloo" in x["desc"] and "mtr_comm_init failed on a rank" in x["desc"] and "no answer from RCCL" in x["desc"] for x in r)
+        assert all(x["took"] < 30 for x in r)
+    elif scenario == "probe-fails":
+        # every rank built a communicator, the FIRST collective on it hung on one: all give theirs up and fall back together
+        assert not any(x["comm"] or x["group"] for x in r)
+        assert all("gloo" in x["desc"] and "first all-reduce on the engine's communicator failed" in x["desc"] for x in r)
+        assert r[0]["closed"] == r[1]["closed"] == 1
     else:
         assert not any(x["comm"] or x["group"] for x in r)
         assert all("gloo" in x["desc"] and "mtr_comm_init failed on a rank" in x["desc"] for x in r)

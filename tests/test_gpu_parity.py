@@ -8,6 +8,8 @@ Tolerances (stated once, used everywhere below):
     within float rounding of a bin edge) may move I by < 0.01 dB and an LRA edge by 0.1 dB.
   * fragment mean powers: 2e-5 relative (time-parallel summation order differs from the serial loop).
   * true peak: 2e-6 relative (FMA / accumulation order).
+  * true-peak ballistics (TruePeakdsp::process: level m and raw peak p of every call): 4e-6 RELATIVE TO THE VALUE ITSELF
+    (3.5e-5 dB), at any level — never "of max (1, value)".
   * band levels of the 30-band bank: 1e-3 dB above -90 dB.
   * integer histograms: identical except for bin-edge flips (a fragment's loudness within ~1e-6 relative of a
     0.1 dB edge: the time-parallel power sum differs from the serial one in the last bits): at most 2 points
@@ -31,6 +33,7 @@ G = np.load(os.path.join(HERE, "golden", "golden_v1.npz"))
 
 DB_TOL = 1e-3
 CONTRACT_DB = 0.01
+TPB_REL = 4e-6             # TruePeakdsp::process, level and peak of a call: relative to the value (jmeters/truepeakdsp.cc:58-84)
 MOVED_MAX = 2              # histogram points in a neighbouring 0.1 dB bin, at most, whatever the count: ONE bound for every check in this file
 
 
@@ -403,7 +406,10 @@ def test_truepeak_ballistics_many_streams(M, oracle, chn, S, T):
     tail, three calls of odd sizes, mono and stereo engines; sampled streams against the oracle."""
     import ctypes as C
     from _oracle import MoTp
-    base = np.stack([sig.lcg_noise(T, 700 + s, 2.0 ** -(s % 4)) for s in range(131)])  # [131][T][2]
+    # levels from full scale down: 2^-(s % 4), and -40 / -60 / -80 dBFS on streams 5, 6, 7 (mod 8) — the gate below is RELATIVE
+    # to the value (VERDICT r4: 2e-6 of max (1, value) is 0.017 dB at a level of 1e-3, outside the +-0.01 dB contract)
+    quiet = {5: 1e-2, 6: 1e-3, 7: 1e-4}
+    base = np.stack([sig.lcg_noise(T, 700 + s, 2.0 ** -(s % 4) * quiet.get(s % 8, 1.0)) for s in range(131)])  # [131][T][2]
     x = base if S == 131 else base[np.arange(S) % 131] * (1.0 + (np.arange(S) // 131)[:, None, None].astype(np.float32) / 64)
     feed = x if chn == 2 else np.ascontiguousarray(x[:, :, 0])
     cuts = (0, 17, 2400 if T > 2400 else 700, T)
@@ -413,7 +419,7 @@ def test_truepeak_ballistics_many_streams(M, oracle, chn, S, T):
             e.process(np.ascontiguousarray(feed[:, a:b]))
             r = e.results()
             got.append([[(r[s].tpb_level[c], r[s].tpb_peak[c]) for c in range(chn)] for s in range(S)])
-    for s in (0, 1, 31, 32, 63, 64, 65, 127, 128, 130) + ((4095, 8191, 8192, S - 1) if S > 131 else ()):
+    for s in (0, 1, 5, 6, 7, 31, 32, 63, 64, 65, 127, 128, 130) + ((4095, 8191, 8192, S - 1) if S > 131 else ()):
         for c in range(chn):
             ch = np.ascontiguousarray(x[s, :, c])
             t = MoTp()
@@ -423,8 +429,8 @@ def test_truepeak_ballistics_many_streams(M, oracle, chn, S, T):
                 seg = np.ascontiguousarray(ch[a:b])
                 oracle.lib.mo_tp_process(C.byref(t), seg, seg.size)
                 oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
-                assert abs(got[i][s][c][0] - m.value) < 2e-6 * max(1.0, m.value), (s, c, i, got[i][s][c][0], m.value)
-                assert abs(got[i][s][c][1] - p.value) < 2e-6 * max(1.0, p.value), (s, c, i)
+                assert abs(got[i][s][c][0] - m.value) <= TPB_REL * m.value + 1e-37, (s, c, i, got[i][s][c][0], m.value)
+                assert abs(got[i][s][c][1] - p.value) <= TPB_REL * p.value + 1e-37, (s, c, i, got[i][s][c][1], p.value)
 
 
 def test_truepeak_ballistics_batch(M, oracle):
@@ -449,8 +455,8 @@ def test_truepeak_ballistics_batch(M, oracle):
                 seg = np.ascontiguousarray(ch[a:b])
                 oracle.lib.mo_tp_process(C.byref(t), seg, seg.size)
                 oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
-                assert abs(got[i][s][c][0] - m.value) < 2e-6 * max(1.0, m.value), (s, c, i)
-                assert abs(got[i][s][c][1] - p.value) < 2e-6 * max(1.0, p.value), (s, c, i)
+                assert abs(got[i][s][c][0] - m.value) <= TPB_REL * m.value + 1e-37, (s, c, i, got[i][s][c][0], m.value)
+                assert abs(got[i][s][c][1] - p.value) <= TPB_REL * p.value + 1e-37, (s, c, i, got[i][s][c][1], p.value)
 
 
 def test_truepeak_ballistics_column_scale_moves(M, oracle):
@@ -507,8 +513,8 @@ def test_truepeak_ballistics_column_scale_moves(M, oracle):
                     if ch == 1:
                         assert np.isfinite(gm) and np.isfinite(gp), (i, gm, gp)
                     continue
-                assert abs(gm - mm) <= 4e-6 * mm + 1e-37, (s, ch, i, gm, mm)
-                assert abs(gp - pp) <= 4e-6 * pp + 1e-37, (s, ch, i, gp, pp)
+                assert abs(gm - mm) <= TPB_REL * mm + 1e-37, (s, ch, i, gm, mm)
+                assert abs(gp - pp) <= TPB_REL * pp + 1e-37, (s, ch, i, gp, pp)
 
 
 @pytest.mark.parametrize("chn", [2, 1])
@@ -579,8 +585,8 @@ def test_truepeak_ballistics_full_size_properties(M, oracle):
                 oracle.lib.mo_tp_process(C.byref(t), seg, seg.size)
                 oracle.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
                 mm, pp = max(mm, m.value), max(pp, p.value)
-            assert abs(a[s, c] - mm) < 2e-6 * max(1.0, mm), (s, c, a[s, c], mm)
-            assert abs(a[s, 2 + c] - pp) < 2e-6 * max(1.0, pp), (s, c, a[s, 2 + c], pp)
+            assert abs(a[s, c] - mm) <= TPB_REL * mm + 1e-37, (s, c, a[s, c], mm)
+            assert abs(a[s, 2 + c] - pp) <= TPB_REL * pp + 1e-37, (s, c, a[s, 2 + c], pp)
     small = torch.stack([buf[s] for s in pick])
     assert np.array_equal(run(small.data_ptr(), len(pick)), a[pick])    # the same audio at another batch index: the same numbers
     buf.mul_(2.0)

@@ -35,6 +35,35 @@ def test_world_of_one_is_the_identity():
         M.Comm(2, 2, M.comm_unique_id(), 0)                   # rank outside the world
 
 
+def test_world_of_one_with_a_deadline():
+    """mtr_comm_init_timeout / mtr_comm_probe / mtr_engine_reduce on a NON-BLOCKING communicator (ncclCommInitRankConfig with
+    blocking = 0, every call polled through ncclCommGetAsyncError): the path bench.py takes at N > 1, on the one GPU a box has."""
+    import torch
+    import meters.lv2_amd as M
+    S, T, fs = 16, 48000 * 2, 48000.0
+    buf = torch.empty((S, T, 2), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    M.synth_fill_device(buf.data_ptr(), S, T, T, 33, fs, 1, st)
+    h0 = torch.zeros(2 * 751, dtype=torch.int32, device="cuda")
+    m0 = torch.zeros(4, dtype=torch.float32, device="cuda")
+    h1, m1 = torch.zeros_like(h0), torch.zeros_like(m0)
+    assert M.engine.rccl_version() >= 21800
+    with M.Comm(0, 1, M.comm_unique_id(), 0, timeout_ms=60000) as comm, M.Engine(S, fs, M.METER_EBU | M.METER_TRUEPEAK) as e:
+        assert 0 < comm.init_ms < 60000
+        assert 0 < comm.probe(30000) < 30000                  # the first collective, bounded
+        comm.set_timeout(20000)
+        e.integr_start()
+        for _ in range(3):
+            e.process_device(buf.data_ptr(), T, T, st)
+            e.aggregate_device(h0.data_ptr(), m0.data_ptr(), st)
+            e.reduce(comm, h1.data_ptr(), m1.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert int(h0.sum()) > 0 and torch.equal(h0, h1) and torch.equal(m0, m1)
+    with M.Comm(0, 1, M.comm_unique_id(), 0) as blocking:
+        with pytest.raises(M.EngineError):
+            blocking.set_timeout(1000)                        # a blocking communicator has no deadline to set
+
+
 def test_two_ranks_against_one_engine():
     import torch
     if torch.cuda.device_count() < 2:

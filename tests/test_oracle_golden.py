@@ -76,6 +76,21 @@ def test_truepeak(oracle):
     assert int(np.argmax(np.abs(oracle.tp_resample(imp)))) == 96
 
 
+def test_golden_v2_ballistics_and_nan(oracle):
+    """golden_v2.npz (round 5, written by make_golden.py v2 from the reference build): TruePeakdsp::process at 44.1 / 96 kHz and at
+    -40 / -60 / -80 dBFS, and the 4x stream around a NaN — the restatement reproduces every array bit for bit."""
+    from make_golden import nan_cases, tpb_cases
+    G2 = np.load(os.path.join(HERE, "golden", "golden_v2.npz"))
+    for name, fs, block, x in tpb_cases():
+        assert np.array_equal(_bits(oracle.tp_process_seq(x, fs, block)), _bits(G2[name])), name
+    for k, x in nan_cases().items():
+        y = oracle.tp_resample(x)
+        assert np.array_equal(np.isnan(y), np.isnan(G2["tp_nan_%s_out" % k])), k
+        ok = ~np.isnan(y)
+        assert np.array_equal(_bits(y[ok]), _bits(G2["tp_nan_%s_out" % k][ok])), k
+        assert np.array_equal(_bits(oracle.tp(np.stack([x, x], 1), 48000.0, 1024)), _bits(G2["tp_nan_%s_peak" % k])), k
+
+
 def test_filter_bank(oracle):
     r = oracle.spectr(sig.lcg_noise(48000, 42, 0.5), 48000.0, 1024)
     for k in ("val", "max", "val_db", "max_db"):

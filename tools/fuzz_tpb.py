@@ -11,7 +11,7 @@ from _oracle import Oracle, MoTp
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 orc = Oracle()
-TOL = 4e-6          # level and peak, relative to max (1, value): the tests' cases hold 2e-6; at 192 kHz the longer memory of the filters shows (2.2e-6)
+TOL = 4e-6          # level and peak, RELATIVE TO THE VALUE (the levels drawn below go down to 2^-13: a bound on max (1, value) would say nothing)
 bad = 0
 worst = {}
 for seed in range(first, first + count):
@@ -55,9 +55,9 @@ for seed in range(first, first + count):
                         seg = np.ascontiguousarray(ch[o:min(o + 8192, pos + n)])
                         orc.lib.mo_tp_process(C.byref(t), seg, seg.size); orc.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
                         mm, pp = max(mm, m.value), max(pp, p.value)
-                    worst[fs] = max(worst.get(fs, 0.0), abs(got[i][s][c][0] - mm) / max(1.0, mm), abs(got[i][s][c][1] - pp) / max(1.0, pp))
-                    assert abs(got[i][s][c][0] - mm) < TOL * max(1.0, mm), ("m", s, c, i, got[i][s][c][0], mm)
-                    assert abs(got[i][s][c][1] - pp) < TOL * max(1.0, pp), ("p", s, c, i, got[i][s][c][1], pp)
+                    worst[fs] = max(worst.get(fs, 0.0), abs(got[i][s][c][0] - mm) / max(1e-37, mm), abs(got[i][s][c][1] - pp) / max(1e-37, pp))
+                    assert abs(got[i][s][c][0] - mm) <= TOL * mm + 1e-37, ("m", s, c, i, got[i][s][c][0], mm)
+                    assert abs(got[i][s][c][1] - pp) <= TOL * pp + 1e-37, ("p", s, c, i, got[i][s][c][1], pp)
                     pos += n
     except AssertionError as ex:
         bad += 1
