@@ -248,7 +248,13 @@ static int state_init (mtr_engine* e, int what, hipStream_t st)
 extern "C" {
 
 const char* mtr_last_error (void) { return g_err.c_str (); }
+// A library built with MTR_TIMING_ONLY_BUILD may carry kernels with a role switched off (tools/: elimination runs that price a
+// part of a kernel — WRONG RESULTS by construction): it says so here, and meters.lv2_amd/engine.py refuses to load it outside tools/.
+#ifdef MTR_TIMING_ONLY_BUILD
+const char* mtr_version (void) { return "meters.lv2_amd 0.1 (gfx950) TIMING-ONLY BUILD: results are wrong by construction"; }
+#else
 const char* mtr_version (void) { return "meters.lv2_amd 0.1 (gfx950)"; }
+#endif
 int mtr_abi_version (void) { return MTR_ABI_VERSION; }
 
 int mtr_kweight_coef (float sample_rate, float* out7)

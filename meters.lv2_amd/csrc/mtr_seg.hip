@@ -203,24 +203,6 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 	typedef f4v_ float4_a8 __attribute__ ((aligned (8)));              // (a segment may start on any frame: 8-byte alignment is all there is)
 	const float4_a8* lp = reinterpret_cast<const float4_a8*> (src + F0 - (warm ? (int64_t) a.warm_steps * R : 0));
 	v2f xq[4][R];
-#ifdef MTR_SEG_DBG_COOP
-	// (timing probe only, WRONG DATA: instruction i reads whole lines — lanes 8 k .. 8 k + 7 the eight chunks of the line of
-	// lane 8 i + k — to price the address pipeline's share of a step: 64 line fragments per instruction against 8 lines)
-	const float4_a8* lpc[R / 2];
-#pragma unroll
-	for (int i = 0; i < R / 2; ++i) {
-		const int from = 8 * i + (lane >> 3);
-		const uint64_t pv = reinterpret_cast<uint64_t> (lp);
-		const uint32_t lo = (uint32_t) __shfl ((int) (uint32_t) pv, from), hi = (uint32_t) __shfl ((int) (uint32_t) (pv >> 32), from);
-		lpc[i] = reinterpret_cast<const float4_a8*> (((uint64_t) hi << 32) | lo) + (lane & 7);
-	}
-	const float4_a8* const lp0 = lp;
-	auto load = [&]<int B> () __attribute__ ((always_inline)) {
-		const int64_t d = lp - lp0;
-#pragma unroll
-		for (int i = 0; i < R / 2; ++i) { const f4v_ v = lpc[i][d]; xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w}; }
-	};
-#else
 	auto load = [&]<int B> () __attribute__ ((always_inline)) {
 #pragma unroll
 		for (int i = 0; i < R / 2; ++i) {
@@ -228,7 +210,6 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 			xq[B][2 * i] = v2f{v.x, v.y}; xq[B][2 * i + 1] = v2f{v.z, v.w};
 		}
 	};
-#endif
 	load.template operator()<0> (); lp += R / 2;
 	load.template operator()<1> (); lp += R / 2;
 	load.template operator()<2> (); lp += R / 2;
@@ -479,7 +460,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 		}
 
 		// the stream, three steps ahead (the pointer stops with the segment: the last loads re-read its last line)
-#ifndef MTR_SEG_DBG_NOADV                                         /* (elimination runs, tools/seg_ab.sh: the same line over and over) */
+#if !(defined (MTR_TIMING_ONLY_BUILD) && defined (MTR_SEG_DBG_NOADV))   /* (elimination runs of a timing-only library, wrong results: the same line over and over) */
 		lp += (j + 3 < (ALIGNED ? n_steps : n_loads)) ? R / 2 : 0;
 #endif
 		load.template operator()<(U + 3) & 3> ();
@@ -512,7 +493,7 @@ __global__ __launch_bounds__ (64, 1) void k_seg (const mtr_seg_args a)
 			constexpr int PB = (BC + 7) & 7;
 			const v2f xa = x[2 * BC], xb = x[2 * BC + 1];
 			if (PROD && BC < 7) fetch.template operator()<U> (Bn, BC + 1);
-#ifdef MTR_SEG_DBG_NOPROD                                        /* (elimination runs: no products) */
+#if defined (MTR_TIMING_ONLY_BUILD) && defined (MTR_SEG_DBG_NOPROD)    /* (elimination runs of a timing-only library, wrong results: no products) */
 #define MTR_M(I)
 #else
 #define MTR_M(I) if (PROD) m16::block_mfma<I> (A, Bc, yc)

@@ -15,7 +15,7 @@
 //   * `if (v > z) z += w (v - z)` is z <- max (z, a z + w v) with a = 1 - w: a monotone max-affine map, and maps of
 //     that kind compose.  The intercepts depend on the values only — any lane can form them, for any frame — so what is
 //     left ON the chain per frame and filter is the release, two fused multiply-adds and a v_max3, twice (the frame's
-//     four values as two pair maps, see below; round 3 applied them as one five-piece map, MTR_TPB_PAIRMAPS = 0).  Exact
+//     four values as two pair maps, see below; round 3 applied them as one five-piece map).  Exact
 //     in real arithmetic; in f32 a few ulps from the reference's sequence (held to the 2e-6 of
 //     tests/test_gpu_parity.py::test_truepeak_ballistics_*; 600 fuzzed shapes: <= 7.4e-7 up to 48 kHz, 1.6e-6 at 192 kHz).
 //   * the interpolator is the matrix-pipe one of mtr_mfma16_fir.h (samples and taps as two f16 halves, three partial
@@ -46,9 +46,8 @@
 //     units on waves 4, 9, 10, 7 (two B and an A on SIMDs 1 and 2, an A beside the chains, an A beside the split); wave 3
 //     sends chunk t + 3 on its way and splits chunk t + 1; waves 8 and 11 only keep the barriers' count.  One barrier per
 //     chunk; the chains (~1400 cycles per chunk) are what bounds it now.
-//     (MTR_TPB_PROD_WAVES = 4 / 2, MTR_TPB_FUSED = 0, MTR_TPB_PAIRMAPS = 0, MTR_TPB_MAP_SPLIT, MTR_TPB_PROD_SET, MTR_TPB_UNIT_*_SET,
-//     MTR_TPB_CHAIN_PRIO and the MTR_TPB_DBG_* switches build the forms this one was measured against: tools/tpb_prof.hip,
-//     profiles/r04_tpb.md, r04_tpb_experiments.md.)
+//     (The forms this one was measured against — one or two blocks per products wave, values and five-piece maps through
+//     LDS, map waves — live in git and in profiles/r04_tpb.md, r04_tpb_experiments.md; ONE form ships.)
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -66,15 +65,14 @@ __device__ unsigned long long g_tpb_prof[12][4];
 #define PROF_ADD(i, d)
 #endif
 
-// (tools/tpb_prof.hip elimination builds: a role switched off — wrong results, timing only)
+// tools/tpb_prof.hip elimination builds — a role switched off: WRONG RESULTS, timing only.  They exist only in a library built
+// with MTR_TIMING_ONLY_BUILD, whose mtr_version () says so and which meters.lv2_amd/engine.py refuses to load outside tools/.
+#ifdef MTR_TIMING_ONLY_BUILD
 #ifndef MTR_TPB_DBG_NOCHAIN
 #define MTR_TPB_DBG_NOCHAIN 0
 #endif
 #ifndef MTR_TPB_DBG_NOPROD
 #define MTR_TPB_DBG_NOPROD 0
-#endif
-#ifndef MTR_TPB_DBG_NOMAPS
-#define MTR_TPB_DBG_NOMAPS 0
 #endif
 #ifndef MTR_TPB_DBG_NOFETCH
 #define MTR_TPB_DBG_NOFETCH 0
@@ -82,29 +80,20 @@ __device__ unsigned long long g_tpb_prof[12][4];
 #ifndef MTR_TPB_DBG_NOSPLIT
 #define MTR_TPB_DBG_NOSPLIT 0
 #endif
-#ifndef MTR_TPB_DBG_NOPUT
-#define MTR_TPB_DBG_NOPUT 0
-#endif
 #ifndef MTR_TPB_DBG_NODMA
 #define MTR_TPB_DBG_NODMA 0
 #endif
-// MTR_TPB_FUSED = 1: the lanes that produce a frame's four values form its maps too (pair maps: ten instructions per frame)
-// and write them where the chains read them — no values in LDS, no map waves, one chunk less between products and chains
-#ifndef MTR_TPB_FUSED
-#define MTR_TPB_FUSED 1
-#endif
-#ifndef MTR_TPB_PAIRMAPS
-#define MTR_TPB_PAIRMAPS 1
+#else
+#define MTR_TPB_DBG_NOCHAIN 0
+#define MTR_TPB_DBG_NOPROD 0
+#define MTR_TPB_DBG_NOFETCH 0
+#define MTR_TPB_DBG_NOSPLIT 0
+#define MTR_TPB_DBG_NODMA 0
 #endif
 
 namespace {
 
-#ifndef MTR_TPB_PROD_WAVES
-#define MTR_TPB_PROD_WAVES 8
-#endif
-// MTR_TPB_PROD_WAVES = 8 (needs MTR_TPB_FUSED): twelve waves, three per SIMD, and a block's products in TWO units on two waves —
-// unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1); unit B: phases 2 and 3 (12 MFMAs) and the second
-constexpr int NW = MTR_TPB_PROD_WAVES == 8 ? 12 : 8;   // wave 0: the chains; wave 3: fetch + split; the others: products (+ maps) or idle
+constexpr int NW = 12;                         // wave 0: the chains; wave 3: fetch + split; eight product units; two idle
 constexpr int F = 16;                          // frames per chunk = rows of one MFMA block
 constexpr int NCOL = 64;                       // (stream, channel) columns per workgroup: 32 stereo or 64 mono streams
 constexpr int RING = 5 * F;                    // samples per column: the 64-sample window of a chunk + the chunk being fetched
@@ -114,42 +103,17 @@ constexpr int HSTRIDE = 176;                   // bytes per column and array of 
                                                // 11 c mod 16 is a permutation — sixteen columns' pieces sit in sixteen bank groups
 constexpr int HRING_B = NCOL * HSTRIDE;        // one array: hi | lo
 constexpr int AUX_B = 512;                     // float un [NCOL]; int flag [2]
-constexpr int VBUF_B = MTR_TPB_FUSED ? 0 : F * NCOL * 16;   // a chunk of values: [frame][column] x (|x[n - 24]|, |y1|, |y2|, |y3|) — only where map waves read them
 constexpr int CBUF_B = F * 2 * NCOL * 16;      // a chunk of maps: [frame][half][column] x (c_k of filter 1, of filter 2) for k = 1, 2 | 3, 4
 constexpr int STG_B = 3 * 4 * 64 * 16;         // three chunks in flight from HBM, as the LDS-DMA leaves them: [chunk][piece 64 i + lane] x 16 bytes
-constexpr int LDS_BYTES = RING_B + 2 * HRING_B + AUX_B + 2 * VBUF_B + 2 * CBUF_B + STG_B;
+constexpr int LDS_BYTES = RING_B + 2 * HRING_B + AUX_B + 2 * CBUF_B + STG_B;
 constexpr int NTHREADS = 64 * NW;
 static_assert (RING % 8 == 0 && (RSTRIDE * 4) % 16 == 0, "operand slices never wrap inside the ring");
 static_assert (LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
-// who forms the maps of which frames of a chunk (waves w and w + 4 share a SIMD: the chains' SIMD and the products' get
-// fewer frames than the fetch wave's)
-// MTR_TPB_PROD_WAVES = 2: waves 1, 2 run two blocks of products each; waves 4, 5, 6, 7, 3 the maps of MAPF[0..1), [1..2), ... [4..5)
-//                    = 4: waves 1, 2, 5, 6 run one block each (two products waves per SIMD cover each other's latencies);
-//                         waves 4, 7, 3 the maps of MAPF[0..1), [1..2), [2..3)
-#ifndef MTR_TPB_MAP_SPLIT
-#if MTR_TPB_PROD_WAVES == 2
-#define MTR_TPB_MAP_SPLIT 0, 2, 6, 10, 13, 16
-#else
-#define MTR_TPB_MAP_SPLIT 0, 3, 10, 16, 16, 16
-#endif
-#endif
-constexpr int MAPF[6] = { MTR_TPB_MAP_SPLIT };
-constexpr int PW = MTR_TPB_PROD_WAVES;
-// PW == 4: the waves that run blocks 0 .. 3 (waves w and w + 4 share a SIMD; wave 0 = the chains, wave 3 = fetch + split)
-#ifndef MTR_TPB_PROD_SET
-#define MTR_TPB_PROD_SET 1, 2, 5, 6
-#endif
-constexpr int PSET[4] = { MTR_TPB_PROD_SET };
-// PW == 8: the waves of unit A (phase 1) and unit B (phases 2, 3) of blocks 0 .. 3: three waves per SIMD (w % 4), the 30 MFMAs of
-// two B units and an A unit on SIMDs 1 and 2, an A unit beside the chains and one beside the split
-#ifndef MTR_TPB_UNIT_A_SET
-#define MTR_TPB_UNIT_A_SET 4, 9, 10, 7
-#endif
-#ifndef MTR_TPB_UNIT_B_SET
-#define MTR_TPB_UNIT_B_SET 1, 5, 2, 6
-#endif
-constexpr int ASET[4] = { MTR_TPB_UNIT_A_SET }, BSET[4] = { MTR_TPB_UNIT_B_SET };
+// A block's products run as two units on two waves — unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1);
+// unit B: phases 2 and 3 (12 MFMAs) and the second — three waves per SIMD (w % 4): the 30 MFMAs of two B units and an A unit
+// on SIMDs 1 and 2, an A unit beside the chains and one beside the split
+constexpr int ASET[4] = { 4, 9, 10, 7 }, BSET[4] = { 1, 5, 2, 6 };
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
 __device__ __forceinline__ v2f fma2 (v2f a, v2f b, v2f c) { return __builtin_elementwise_fma (a, b, c); }
@@ -183,8 +147,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	unsigned char* const ringl = ringh + HRING_B;                        // ... lo
 	float* const un_sh = reinterpret_cast<float*> (ringl + HRING_B);     // [NCOL]: 2^-15 / scale of every column, as the ring holds it
 	int* const flag_sh = reinterpret_cast<int*> (un_sh + NCOL);          // [2]: a rescale is pending for the iteration of this parity
-	unsigned char* const vbuf = smem + RING_B + 2 * HRING_B + AUX_B;     // [2][F][NCOL] float4
-	unsigned char* const cbuf = vbuf + 2 * VBUF_B;                       // [2][F][2][NCOL] float4
+	unsigned char* const cbuf = smem + RING_B + 2 * HRING_B + AUX_B;     // [2][F][2][NCOL] float4
 	const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
 	const uint32_t s0 = blockIdx.x * NSTR;
 	const int64_t n_frames = (int64_t) a.n_frames;
@@ -254,7 +217,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		for (int i = 0; i < NP; ++i) {
 			const float* const g = dsrc[i] + (size_t) j * (F * C);
 			const uint32_t l = stg_lds + (uint32_t) (buf * NP + i) * 1024u;
-			asm volatile ("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(l) : "memory");       // (m0 is reserved: the compiler writes it right in front of whatever needs it and keeps nothing there)
+			// (m0 is saved and restored inside the statement: the compiler may keep a value of its own there — it does not accept m0 on
+			// a clobber list — and the LDS-DMA reads its LDS base from it)
+			uint32_t m0_was;
+			asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_was) : "v"(g), "s"(l) : "memory");
 		}
 	};
 	auto store = [&] (int i, int slot, float4 v) __attribute__ ((always_inline)) {
@@ -394,13 +360,13 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	};
 
 	const v2f AA = v2f{a1, a2};
-	// ---- the products (waves 1, 2: two blocks each) and the per-frame maps (lane = column) ------------------------------------
+	// ---- the products and the per-frame maps: lane (cc, kg) = column cc of the block, frames 4 kg .. + 3 of the chunk ---------
 	const int cc = lane & 15, kg = lane >> 4;
 	m16::AFrag A;
-	const int unit_a = PW == 8 ? (wid == ASET[0] ? 0 : wid == ASET[1] ? 1 : wid == ASET[2] ? 2 : wid == ASET[3] ? 3 : -1) : -1;
-	const int unit_b = PW == 8 ? (wid == BSET[0] ? 0 : wid == BSET[1] ? 1 : wid == BSET[2] ? 2 : wid == BSET[3] ? 3 : -1) : -1;
-	const int my_block = PW == 4 ? (wid == PSET[0] ? 0 : wid == PSET[1] ? 1 : wid == PSET[2] ? 2 : wid == PSET[3] ? 3 : -1) : PW == 8 ? (unit_a >= 0 ? unit_a : unit_b) : -1;
-	const bool prod_wave = PW == 2 ? (wid == 1 || wid == 2) : my_block >= 0;
+	const int unit_a = wid == ASET[0] ? 0 : wid == ASET[1] ? 1 : wid == ASET[2] ? 2 : wid == ASET[3] ? 3 : -1;
+	const int unit_b = wid == BSET[0] ? 0 : wid == BSET[1] ? 1 : wid == BSET[2] ? 2 : wid == BSET[3] ? 3 : -1;
+	const int my_block = unit_a >= 0 ? unit_a : unit_b;
+	const bool prod_wave = my_block >= 0;
 	if (prod_wave) {
 		A.load (a.mfma_a, lane);
 		// (used — waited for — right here: a load still pending where the roles part makes the compiler guard every register it
@@ -408,61 +374,9 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 #pragma unroll
 		for (int f = 0; f < MTR_M16_FRAGS; ++f) asm volatile ("" : "+v"(A.a[f]));
 	}
-	// values of chunk j, blocks b0, b0 + 1 (columns 16 b + cc; this lane: frames 4 kg .. + 3) -> vbuf
-	float pk[2] = { 0.f, 0.f };                                          // raw peaks of the values this lane produced (column cc of its blocks)
-	auto products = [&]<int NB> (int par, int w0, int b0, int nfl) {     // w0 = ring position of window position 0 = frame 16 j - 48; par = j & 1;
-	                                                                     // nfl = how many of this lane's four frames belong to the call
-		m16::BFrag B[NB];
-		float4 x0[NB];                                                   // x[n - 24] of this lane's four frames, exact
-		float un[NB];
-		// window positions 32 st + 8 kg .. + 7 = the 16-byte piece (w0 / 8 + 4 st + kg) mod 10 of the column
-		int q0 = (w0 >> 3) + kg; q0 -= q0 >= 10 ? 10 : 0;
-		int q1 = q0 + 4; q1 -= q1 >= 10 ? 10 : 0;
-#pragma unroll
-		for (int n = 0; n < NB; ++n) {
-			const int col = 16 * (b0 + n) + cc;
-			const unsigned char* const h = ringh + col * HSTRIDE;
-			const unsigned char* const l = ringl + col * HSTRIDE;
-			B[n].h0 = *reinterpret_cast<const uint4*> (h + 16 * q0);
-			B[n].h1 = *reinterpret_cast<const uint4*> (h + 16 * q1);
-			B[n].l0 = *reinterpret_cast<const uint4*> (l + 16 * q0);
-			B[n].l1 = *reinterpret_cast<const uint4*> (l + 16 * q1);
-			int o0 = w0 + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0;
-			x0[n] = *reinterpret_cast<const float4*> (ring + col * RSTRIDE + o0);
-			un[n] = un_sh[col];
-		}
-		m16::f4 y[NB][3];
-#pragma unroll
-		for (int n = 0; n < NB; ++n) m16::block (A, B[n], y[n]);
-#pragma unroll
-		for (int n = 0; n < NB; ++n) {
-			unsigned char* const dst = vbuf + par * VBUF_B + ((4 * kg) * NCOL + 16 * (b0 + n) + cc) * 16;
-			(void) dst;
-			const float xr[4] = { x0[n].x, x0[n].y, x0[n].z, x0[n].w };
-			float pm = 0.f, px = 0.f;
-#pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				const float keep = r < nfl ? 1.f : 0.f;
-				px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
-				pm = __builtin_fmaxf (pm, max3f (fabsf (y[n][0][r]), fabsf (y[n][1][r]), fabsf (y[n][2][r])) * keep);      // truepeakdsp.cc:65
-#if MTR_TPB_FUSED && MTR_TPB_PAIRMAPS
-				{
-					const v2f W = v2f{a.w1, a.w2};
-					const v2f b1 = W * fabsf (xr[r]), b2 = W * (fabsf (y[n][0][r]) * un[n]), b3 = W * (fabsf (y[n][1][r]) * un[n]), b4 = W * (fabsf (y[n][2][r]) * un[n]);
-					const v2f d1 = max2 (b1, b2), d2 = fma2 (AA, b1, b2), e1 = max2 (b3, b4), e2 = fma2 (AA, b3, b4);
-					unsigned char* const cd = cbuf + par * CBUF_B + (((4 * kg + r) * 2) * NCOL + 16 * (b0 + n) + cc) * 16;
-					*reinterpret_cast<float4*> (cd) = float4{d1.x, d1.y, d2.x, d2.y};
-					*reinterpret_cast<float4*> (cd + NCOL * 16) = float4{e1.x, e1.y, e2.x, e2.y};
-				}
-#else
-				*reinterpret_cast<float4*> (dst + r * NCOL * 16) = float4{fabsf (xr[r]), fabsf (y[n][0][r]) * un[n], fabsf (y[n][1][r]) * un[n], fabsf (y[n][2][r]) * un[n]};
-#endif
-			}
-			pk[n] = max3f (pk[n], px, pm * un[n]);
-		}
-	};
+	float pk[2] = { 0.f, 0.f };                                          // raw peak of the values this lane produced (column cc of its block)
 
-	// PW == 8: one of the two units of a block (UB = false: phase 1 + the first pair map; true: phases 2, 3 + the second)
+	// one of the two units of a block (UB = false: phase 1 + the first pair map; true: phases 2, 3 + the second)
 	auto unit = [&]<bool UB> (int par, int w0, int b, int nfl) __attribute__ ((always_inline)) {
 		int q0 = (w0 >> 3) + kg; q0 -= q0 >= 10 ? 10 : 0;
 		int q1 = q0 + 4; q1 -= q1 >= 10 ? 10 : 0;
@@ -517,53 +431,6 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		pk[0] = max3f (pk[0], px, pm * un);
 	};
 
-#if MTR_TPB_PAIRMAPS
-	// Two attacks in a row are z <- max (z, a z + max (b1, b2), a^2 z + (a b1 + b2)), b = w v: a frame is two such maps, one
-	// after the other on the chain (the release folded into the first one's slopes) — two intercepts per pair and filter, one
-	// fused multiply-add and one maximum each, instead of the four intercepts of the frame's single map (6 + 6).
-	auto maps = [&]<int F0, int F1> (int par) {
-		if constexpr (F1 > F0) {
-		const unsigned char* const src = vbuf + par * VBUF_B + lane * 16;
-		unsigned char* const dst = cbuf + par * CBUF_B + lane * 16;
-		const v2f W = v2f{a.w1, a.w2};
-		float4 va[F1 - F0];
-#pragma unroll
-		for (int f = F0; f < F1; ++f) va[f - F0] = *reinterpret_cast<const float4*> (src + f * NCOL * 16);
-#pragma unroll
-		for (int f = F0; f < F1; ++f) {
-			const v2f b1 = W * va[f - F0].x, b2 = W * va[f - F0].y, b3 = W * va[f - F0].z, b4 = W * va[f - F0].w;
-			const v2f d1 = max2 (b1, b2), d2 = fma2 (AA, b1, b2), e1 = max2 (b3, b4), e2 = fma2 (AA, b3, b4);
-			*reinterpret_cast<float4*> (dst + (f * 2 + 0) * NCOL * 16) = float4{d1.x, d1.y, d2.x, d2.y};
-			*reinterpret_cast<float4*> (dst + (f * 2 + 1) * NCOL * 16) = float4{e1.x, e1.y, e2.x, e2.y};
-		}
-		}
-	};
-#else
-	auto maps = [&]<int F0, int F1> (int par) {
-		if constexpr (F1 > F0) {
-		const unsigned char* const src = vbuf + par * VBUF_B + lane * 16;
-		unsigned char* const dst = cbuf + par * CBUF_B + lane * 16;
-		const v2f W = v2f{a.w1, a.w2};
-		float4 va[F1 - F0];
-#pragma unroll
-		for (int f = F0; f < F1; ++f) va[f - F0] = *reinterpret_cast<const float4*> (src + f * NCOL * 16);
-		v2f g1[F1 - F0], g2[F1 - F0], g3[F1 - F0], g4[F1 - F0];
-#pragma unroll
-		for (int f = F0; f < F1; ++f) {
-			const v2f b1 = W * va[f - F0].x, b2 = W * va[f - F0].y, b3 = W * va[f - F0].z, b4 = W * va[f - F0].w;
-			const v2f d1 = max2 (b1, b2), d2 = fma2 (AA, b1, b2);
-			const v2f e1 = max2 (d1, b3), e2 = max2 (d2, fma2 (AA, d1, b3)), e3 = fma2 (AA, d2, b3);
-			g1[f - F0] = max2 (e1, b4); g2[f - F0] = max2 (e2, fma2 (AA, e1, b4)); g3[f - F0] = max2 (e3, fma2 (AA, e2, b4)); g4[f - F0] = fma2 (AA, e3, b4);
-		}
-#pragma unroll
-		for (int f = F0; f < F1; ++f) {
-			*reinterpret_cast<float4*> (dst + (f * 2 + 0) * NCOL * 16) = float4{g1[f - F0].x, g1[f - F0].y, g2[f - F0].x, g2[f - F0].y};
-			*reinterpret_cast<float4*> (dst + (f * 2 + 1) * NCOL * 16) = float4{g3[f - F0].x, g3[f - F0].y, g4[f - F0].x, g4[f - F0].y};
-		}
-		}
-	};
-#endif
-
 	// ---- prologue: the 48 frames before the call (47 of history; frame -48 is never multiplied by a non-zero tap) and chunk 0 ----
 	if (wid != 0) {
 		for (int e = (wid - 1) * 64 + lane; e < NCOL * 48; e += (NW - 1) * 64) {
@@ -604,8 +471,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	v2f sl2[5];
 #pragma unroll
 	for (int k = 0; k < 5; ++k) sl2[k] = v2f{s1[k], s2[k]};
-	const v2f AA2 = v2f{(float) ((double) a1 * (double) a1), (float) ((double) a2 * (double) a2)};   // (pair maps: the second pair's slopes are a, a^2)
-	(void) AA2;
+	const v2f AA2 = v2f{(float) ((double) a1 * (double) a1), (float) ((double) a2 * (double) a2)};   // (the second pair's slopes are a, a^2)
 	auto chain = [&]<bool FULL> (int par, int nf) {
 		const unsigned char* const src = cbuf + par * CBUF_B + lane * 16;
 		float4 q1[F], q2[F];                                             // the maps do not depend on the state: all sixteen frames' reads go out first
@@ -617,22 +483,15 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 #pragma unroll
 		for (int f = 0; f < F; ++f) {
 			if (FULL || f < nf) {                                            // wave-uniform: only the call's last chunk is short
-#if MTR_TPB_PAIRMAPS
 				const v2f u0 = sl2[0] * zz, u1 = fma2 (sl2[1], zz, v2f{q1[f].x, q1[f].y}), u2 = fma2 (sl2[2], zz, v2f{q1[f].z, q1[f].w});
 				const v2f zh = v2f{max3f (u0.x, u1.x, u2.x), max3f (u0.y, u1.y, u2.y)};
 				const v2f w1_ = fma2 (AA, zh, v2f{q2[f].x, q2[f].y}), w2_ = fma2 (AA2, zh, v2f{q2[f].z, q2[f].w});
 				zz = v2f{max3f (zh.x, w1_.x, w2_.x), max3f (zh.y, w1_.y, w2_.y)};
 				zm = __builtin_fmaxf (zm, zz.x + zz.y);
-				continue;
-#endif
-				const v2f t0 = sl2[0] * zz, t1 = fma2 (sl2[1], zz, v2f{q1[f].x, q1[f].y}), t2 = fma2 (sl2[2], zz, v2f{q1[f].z, q1[f].w}),
-				          t3 = fma2 (sl2[3], zz, v2f{q2[f].x, q2[f].y}), t4 = fma2 (sl2[4], zz, v2f{q2[f].z, q2[f].w});
-				zz = v2f{max3f (max3f (t0.x, t1.x, t2.x), t3.x, t4.x), max3f (max3f (t0.y, t1.y, t2.y), t3.y, t4.y)};
-				zm = __builtin_fmaxf (zm, zz.x + zz.y);
 			}
 		}
 	};
-	constexpr int LAG = MTR_TPB_FUSED ? 1 : 2;                           // chunks between the products and the chains
+	constexpr int LAG = 1;                                               // chunks between the products and the chains
 	// THE LOOP, once per role: every wave runs the same iterations and the same barriers, but each role's copy of the loop has
 	// its own registers (in ONE loop with the roles as branches the compiler re-fetched the products' twelve tap fragments from
 	// global memory in every iteration — the chains' thirty-two map registers were live across the same loop — and a block of
@@ -666,24 +525,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		}
 	};
 	auto run = [&]<bool SPLITTER> (auto&& work) __attribute__ ((always_inline)) { run_range.template operator()<SPLITTER> (0, n_it, work); };
-	auto maps_of = [&]<int F0, int F1, int PAR> (int64_t t) __attribute__ ((always_inline)) {
-		if (!MTR_TPB_FUSED && t >= 1 && t - 1 < n_chunks && !MTR_TPB_DBG_NOMAPS) maps.template operator()<F0, F1> (PAR ^ 1);
-	};
-	auto run_products = [&]<int NB> (int b0) __attribute__ ((always_inline)) {
-		run.template operator()<false> ([&]<int PAR> (int64_t t, int slot_w, int) __attribute__ ((always_inline)) {
-			if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
-				const int64_t left = n_frames - t * F - 4 * kg;                 // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
-				products.template operator()<NB> (PAR, slot_w, b0, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
-			}
-		});
-	};
-	auto run_maps = [&]<int I> () __attribute__ ((always_inline)) {
-		run.template operator()<false> ([&]<int PAR> (int64_t t, int, int) __attribute__ ((always_inline)) { maps_of.template operator()<MAPF[I], MAPF[I + 1], PAR> (t); });
-	};
 	if (wid == 0) {
-#ifdef MTR_TPB_CHAIN_PRIO
-		__builtin_amdgcn_s_setprio (MTR_TPB_CHAIN_PRIO);              // (the chains are the one serial role: let them issue first on their SIMD)
-#endif
 		run.template operator()<false> ([&]<int PAR> (int64_t t, int, int) __attribute__ ((always_inline)) {
 			if (t >= LAG && !MTR_TPB_DBG_NOCHAIN) {
 				const int64_t left = n_frames - (t - LAG) * F;
@@ -709,7 +551,6 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 			else if (younger == 1) asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
 			else                   asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 			if (!MTR_TPB_DBG_NOSPLIT) split_staged (sb1, slot_p, PAR ^ 1);
-			maps_of.template operator()<MAPF[PW == 2 ? 4 : 2], MAPF[PW == 2 ? 5 : 3], PAR> (t);
 		});
 		run_range.template operator()<true> (t_dma, n_it, [&]<int PAR> (int64_t t, int, int slot_p) __attribute__ ((always_inline)) {
 			if (t + 1 < n_chunks && !MTR_TPB_DBG_NOFETCH) {
@@ -717,31 +558,19 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 				wave_sync ();
 				split (slot_p, PAR ^ 1);
 			}
-			maps_of.template operator()<MAPF[PW == 2 ? 4 : 2], MAPF[PW == 2 ? 5 : 3], PAR> (t);
 		});
-	} else if constexpr (PW == 2) {
-		if (wid <= 2) run_products.template operator()<2> (2 * (wid - 1));
-		else if (wid == 4) run_maps.template operator()<0> ();
-		else if (wid == 5) run_maps.template operator()<1> ();
-		else if (wid == 6) run_maps.template operator()<2> ();
-		else run_maps.template operator()<3> ();
-	} else if constexpr (PW == 8) {
-		static_assert (PW != 8 || (MTR_TPB_FUSED && MTR_TPB_PAIRMAPS), "the two-unit form writes pair maps");
+	} else {
 		auto run_unit = [&]<bool UB> (int b) __attribute__ ((always_inline)) {
 			run.template operator()<false> ([&]<int PAR> (int64_t t, int slot_w, int) __attribute__ ((always_inline)) {
 				if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
-					const int64_t left = n_frames - t * F - 4 * kg;
+					const int64_t left = n_frames - t * F - 4 * kg;             // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
 					unit.template operator()<UB> (PAR, slot_w, b, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
 				}
 			});
 		};
 		if (unit_a >= 0) run_unit.template operator()<false> (unit_a);
 		else if (unit_b >= 0) run_unit.template operator()<true> (unit_b);
-		else run_maps.template operator()<0> ();                      // (idle: keeps the barriers' count)
-	} else {
-		if (my_block >= 0) run_products.template operator()<1> (my_block);
-		else if (wid == 4) run_maps.template operator()<0> ();        // (with fused maps: waves without a role only keep the barriers' count)
-		else run_maps.template operator()<1> ();
+		else run.template operator()<false> ([&]<int PAR> (int64_t, int, int) __attribute__ ((always_inline)) { });   // (idle: keeps the barriers' count)
 	}
 	z1 = zz.x; z2 = zz.y;
 #ifdef MTR_TPB_PROF
@@ -752,12 +581,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	uint32_t* const pk_sh = reinterpret_cast<uint32_t*> (ring);          // the ring is spent
 	if (wid == 0) pk_sh[lane] = 0u;
 	__syncthreads ();
-	if (prod_wave) {
-		if (PW == 2) {
-			atomicMax (&pk_sh[32 * (wid - 1) + cc], __float_as_uint (pk[0]));
-			atomicMax (&pk_sh[32 * (wid - 1) + 16 + cc], __float_as_uint (pk[1]));
-		} else atomicMax (&pk_sh[16 * my_block + cc], __float_as_uint (pk[0]));
-	}
+	if (prod_wave) atomicMax (&pk_sh[16 * my_block + cc], __float_as_uint (pk[0]));
 	__syncthreads ();
 	if (wid == 0 && owner) {
 		st->tpb_z1[ch] = z1 + 1e-20f;                                    // truepeakdsp.cc:86-87

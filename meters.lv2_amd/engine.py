@@ -148,6 +148,11 @@ def _load():
 
 
 lib = _load()
+if b"TIMING-ONLY" in lib.mtr_version() and os.environ.get("MTR_ALLOW_TIMING_ONLY_BUILD") != "1":
+    # a library built with -DMTR_TIMING_ONLY_BUILD may carry kernels with a role switched off (tools/: elimination runs): its
+    # results are wrong by construction, and only the timing tools — which set the variable — may load it
+    raise ImportError(f"{lib_path} is a TIMING-ONLY build ({lib.mtr_version().decode()}): it computes wrong results and is only "
+                      "for the elimination runs under tools/ (MTR_ALLOW_TIMING_ONLY_BUILD=1)")
 
 
 def _check(rc, what):
