@@ -93,31 +93,49 @@ __device__ unsigned long long g_tpb_prof[12][4];
 
 namespace {
 
-constexpr int NW = 12;                         // wave 0: the chains; wave 3: fetch + split; eight product units; two idle
+constexpr int NW = 12;                         // waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2, 3: fetch + split of the same halves;
+                                               // 4 .. 7: unit A of blocks 0 .. 3; 8 .. 11: unit B — waves w, w + 4, w + 8 share a SIMD
 constexpr int F = 16;                          // frames per chunk = rows of one MFMA block
 constexpr int NCOL = 64;                       // (stream, channel) columns per workgroup: 32 stereo or 64 mono streams
-constexpr int RING = 5 * F;                    // samples per column: the 64-sample window of a chunk + the chunk being fetched
-constexpr int RSTRIDE = RING + 4;              // floats per column of the f32 ring (16-byte rows; 84 = 20 mod 64: sixteen columns hit sixteen bank groups)
+constexpr int NSLOT = 6;                       // ring slots of 16 samples per column: the 64-sample window of the chunk in the products and
+                                               // the two chunks the split is ahead of it
+constexpr int RING = NSLOT * F;
+constexpr int RSTRIDE = RING + 4;              // floats per column of the f32 ring: 25 x 16 bytes — odd, so that the 16-byte stores of eight
+                                               // neighbouring columns (the split's lanes) sit in eight bank groups
 constexpr int RING_B = NCOL * RSTRIDE * 4;
-constexpr int HSTRIDE = 176;                   // bytes per column and array of the f16 ring: ten 16-byte pieces (8 samples as four pair words) + 16:
-                                               // 11 c mod 16 is a permutation — sixteen columns' pieces sit in sixteen bank groups
+constexpr int HSTRIDE = 256;                   // bytes per column and array of the f16 ring: sixteen 16-byte places for its twelve pieces (8 samples
+                                               // as four pair words each), piece q at place (q + rot (column)) mod 16 — see f16_rot
 constexpr int HRING_B = NCOL * HSTRIDE;        // one array: hi | lo
 constexpr int AUX_B = 512;                     // float un [NCOL]; int flag [2]
-constexpr int CBUF_B = F * 2 * NCOL * 16;      // a chunk of maps: [frame][half][column] x (c_k of filter 1, of filter 2) for k = 1, 2 | 3, 4
-constexpr int STG_B = 3 * 4 * 64 * 16;         // three chunks in flight from HBM, as the LDS-DMA leaves them: [chunk][piece 64 i + lane] x 16 bytes
+constexpr int CROW = 1024;                     // a chunk of maps: [half][frame] rows of [group of 16 columns][filter][column] x (c, c') = 8 bytes
+constexpr int CBUF_B = 2 * F * CROW;
+constexpr int NSTG = 4;                        // chunks on their way from HBM, as the LDS-DMA leaves them: [chunk % 4][piece 64 i + lane] x 16 bytes
+constexpr int STG_B = NSTG * 4 * 1024;
 constexpr int LDS_BYTES = RING_B + 2 * HRING_B + AUX_B + 2 * CBUF_B + STG_B;
 constexpr int NTHREADS = 64 * NW;
 static_assert (RING % 8 == 0 && (RSTRIDE * 4) % 16 == 0, "operand slices never wrap inside the ring");
 static_assert (LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
-// A block's products run as two units on two waves — unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1);
-// unit B: phases 2 and 3 (12 MFMAs) and the second — three waves per SIMD (w % 4): the 30 MFMAs of two B units and an A unit
-// on SIMDs 1 and 2, an A unit beside the chains and one beside the split
-constexpr int ASET[4] = { 4, 9, 10, 7 }, BSET[4] = { 1, 5, 2, 6 };
+// Where piece q of a column sits in its 256 bytes of the f16 ring.  ds_read_b128 is served in the lane groups
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, {32-35, 44-47, 52-59}, {36-43, 48-51, 60-63} (MI355X_MICROARCH.md, LDS), one cycle each
+// while the sixteen 16-byte places differ mod 16.  A products lane (cc, kg) reads piece q0 + kg of column cc: a group holds the
+// columns {0-3, 12-15} of one kg and {4-11} of the next, i.e. two consecutive pieces — so every column's rotation must be EVEN
+// (the two pieces then differ in parity) and distinct within each of the two column sets: rot = (c & 6) + 8 (c & 1).  (Round 4's
+// 176-byte columns put 11 c + kg mod 16 there: three places of every group twice — SQ_LDS_BANK_CONFLICT 1.1e9 per launch, 17.8 % of
+// the LDS-active cycles.)  The split's ds_write_b128 goes in groups of eight NEIGHBOURING lanes whose places must differ mod 8:
+// rot mod 8 = c & 6 takes four values on eight columns, so odd columns write the OTHER piece of a chunk's two in the same
+// instruction (a lane of the split owns half a chunk of its column: which half alternates with the column's parity).
+__device__ __forceinline__ int f16_rot (int col) { return (col & 6) | ((col & 1) << 3); }
+__device__ __forceinline__ int f16_place (int q, int rot) { return ((q + rot) & 15) << 4; }
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
-__device__ __forceinline__ v2f fma2 (v2f a, v2f b, v2f c) { return __builtin_elementwise_fma (a, b, c); }
 __device__ __forceinline__ v2f max2 (v2f a, v2f b) { return v2f{__builtin_fmaxf (a.x, b.x), __builtin_fmaxf (a.y, b.y)}; }
+// the maximum of a value over lanes l and l ^ 32, in both (v_permlane32_swap: the upper half of one operand against the lower of the other)
+__device__ __forceinline__ float max_across_halves (float m)
+{
+	const auto r = __builtin_amdgcn_permlane32_swap (__float_as_uint (m), __float_as_uint (m), false, false);
+	return __builtin_fmaxf (__uint_as_float (r[0]), __uint_as_float (r[1]));
+}
 
 // The scale of a column: a power of two, 2^(se - 127).  Made for a window maximum W it puts W into [2^12, 2^13); it stands
 // until a sample reaches 2^15 under it (cap: the bit pattern of that sample — non-negative floats order as uints, an Inf
@@ -142,66 +160,62 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 {
 	constexpr int NSTR = NCOL / C;                                       // streams per workgroup
 	extern __shared__ __attribute__ ((aligned (16))) unsigned char smem[];
-	float* const ring = reinterpret_cast<float*> (smem);                 // [NCOL][RSTRIDE] f32: exact samples
-	unsigned char* const ringh = smem + RING_B;                          // [NCOL][HSTRIDE]: f16 hi pair words, slot k at 32 k
+	float* const ring = reinterpret_cast<float*> (smem);                 // [NCOL][RSTRIDE] f32: exact samples, chunk j at position 16 ((j + 3) mod 6)
+	unsigned char* const ringh = smem + RING_B;                          // [NCOL][HSTRIDE]: f16 hi pair words, the two pieces of chunk j = 2 ((j + 3) mod 6), + 1
 	unsigned char* const ringl = ringh + HRING_B;                        // ... lo
 	float* const un_sh = reinterpret_cast<float*> (ringl + HRING_B);     // [NCOL]: 2^-15 / scale of every column, as the ring holds it
 	int* const flag_sh = reinterpret_cast<int*> (un_sh + NCOL);          // [2]: a rescale is pending for the iteration of this parity
-	unsigned char* const cbuf = smem + RING_B + 2 * HRING_B + AUX_B;     // [2][F][2][NCOL] float4
+	unsigned char* const cbuf = smem + RING_B + 2 * HRING_B + AUX_B;     // [2][half][frame][CROW]
+	unsigned char* const stg = cbuf + 2 * CBUF_B;
 	const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
 	const uint32_t s0 = blockIdx.x * NSTR;
 	const int64_t n_frames = (int64_t) a.n_frames;
 	const int64_t n_chunks = (n_frames + F - 1) / F;
 
-	// ---- the chains: lane = column ----------------------------------------------------------------------------------------
-	const int ch = C == 2 ? lane >> 5 : 0;
-	const uint32_t sl = s0 + (uint32_t) (C == 2 ? (lane & 31) : lane);
-	const bool owner = sl < a.n_streams;
-	mtr_stream_state* const st = a.state + (owner ? sl : 0);
-	float z1 = 0.f, z2 = 0.f, zm = 0.f;                                  // (the two filters are walked as one packed pair)
-	if (wid == 0 && owner) {
-		z1 = st->tpb_z1[ch]; z2 = st->tpb_z2[ch];
-		z1 = z1 > 20 ? 20 : (z1 < 0 ? 0 : z1);                             // truepeakdsp.cc:54-55
-		z2 = z2 > 20 ? 20 : (z2 < 0 ? 0 : z2);
+	// ---- the chains (waves 0, 1): lane = (column ci of the wave's 32, filter phi) ------------------------------------------
+	// One filter of one column per lane, in plain f32 — round 4 walked both filters of a column as a packed pair in ONE wave of 64
+	// columns: eleven instructions per frame of which five packed; here a wave issues nine unpacked ones, and there are two waves.
+	const int hw_ = wid & 1;                                             // which half of the columns (chains and split alike)
+	const int ci = lane >> 1, phi = lane & 1;
+	const int ccol = 32 * hw_ + ci;
+	const uint32_t csl = s0 + (uint32_t) (C == 2 ? ci : ccol);
+	const int cch = C == 2 ? hw_ : 0;
+	const bool cowner = csl < a.n_streams;
+	mtr_stream_state* const cst = a.state + (cowner ? csl : 0);
+	float z = 0.f, zm = 0.f;
+	if (wid < 2 && cowner) {
+		z = phi ? cst->tpb_z2[cch] : cst->tpb_z1[cch];
+		z = z > 20 ? 20 : (z < 0 ? 0 : z);                                 // truepeakdsp.cc:54-55
 	}
-	// slopes of the frame's map: a^k w3 (the release first, then up to four attacks)
+	// slopes of the frame's two pair maps: w3, a w3, a^2 w3 (the release folded into the first one) | a, a^2
 	const float a1 = 1.0f - a.w1, a2 = 1.0f - a.w2;
-	float s1[5], s2[5];
-	{
-		double p1 = (double) a.w3, p2 = (double) a.w3;
-		for (int k = 0; k < 5; ++k) { s1[k] = (float) p1; s2[k] = (float) p2; p1 *= (double) a1; p2 *= (double) a2; }
-	}
+	const float ap = phi ? a2 : a1;
+	const float sl0 = a.w3, sl1 = (float) ((double) a.w3 * (double) ap), sl2_ = (float) ((double) a.w3 * (double) ap * (double) ap);
+	const float ap2 = (float) ((double) ap * (double) ap);
+	const v2f AA = v2f{a1, a2};
 
-	// ---- wave 3: what it fetches ------------------------------------------------------------------------------------------
-	// A chunk is 256 pieces of 16 bytes: stereo piece p = (stream p / 8, frames 2 (p % 8), + 1), mono piece p = (stream p / 4,
-	// frames 4 (p % 4) .. + 3).  Wave 3 fetches them, four per lane.
-	constexpr int NP = 4;
-	const float* prow[NP];
-	int pfr[NP], pdst[NP];
-	bool plive[NP];
-#pragma unroll
-	for (int i = 0; i < NP; ++i) {
-		const int p = 64 * i + lane;
-		const int row = C == 2 ? p >> 3 : p >> 2;
-		pfr[i] = C == 2 ? 2 * (p & 7) : 4 * (p & 3);
-		plive[i] = s0 + (uint32_t) row < a.n_streams;
-		prow[i] = a.audio + (size_t) (plive[i] ? s0 + (uint32_t) row : s0) * a.stride * C;
-		pdst[i] = row * RSTRIDE + pfr[i];                                // (stereo: the right channel's column is 32 further)
-	}
+	// ---- the split (waves 2, 3): lane = (half hh of the lanes, column cl of the wave's 32); it owns samples 8 hp .. 8 hp + 7 of every chunk ----
+	const int hh = lane >> 5, cl = lane & 31;
+	const int scol = 32 * hw_ + cl;
+	const int hp = hh ^ (cl & 1);                                        // (odd columns: the halves swap lanes — f16_rot)
+	const uint32_t ssl = s0 + (uint32_t) (C == 2 ? cl : scol);
+	const int sch = C == 2 ? hw_ : 0;
+	const bool sowner = ssl < a.n_streams;
+	const float* const srow = a.audio + (size_t) (sowner ? ssl : s0) * a.stride * C;
+	const int srot = f16_rot (scol);
+
 	// A WHOLE chunk travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no register holds data in flight, so nothing
-	// makes the wave wait for it but the one s_waitcnt below), THREE iterations ahead of its products: HBM's latency is
-	// ~2500 cycles under this kernel's access pattern — one 128-byte line per stream and chunk, 1 MB in flight chip-wide per
-	// chunk of prefetch distance — more than a whole chunk's time.  (Rounds 2 and 3 loaded a chunk into registers and used
-	// it in the same iteration; round 4's first forms kept it in registers across the barrier, one and two chunks ahead: the
-	// compiler's wait counts at a loop's back edge are conservative, vmcnt (0), and every form waited for the youngest
-	// loads.  That wait was what bound this kernel: tools/tpb_prof.hip, MTR_TPB_DBG_NOFETCH.)  The lane-linear destination
-	// is the [piece] order the lanes read back.  The call's ragged last chunk, and every chunk of a batch whose streams do
-	// not start on 16 bytes, is loaded and stored in one go.
-	unsigned char* const stg = cbuf + 2 * CBUF_B;
+	// makes the wave wait for it but the one s_waitcnt below), issued by wave 2, THREE iterations ahead of the barrier behind
+	// which the split reads it: HBM's latency is ~2500 cycles under this kernel's access pattern — one 128-byte line per stream
+	// and chunk, 1 MB in flight chip-wide per chunk of prefetch distance — more than a whole chunk's time.  (Rounds 2 and 3 loaded
+	// a chunk into registers and used it in the same iteration; round 4's first forms kept it in registers across the barrier:
+	// the compiler's wait counts at a loop's back edge are conservative, vmcnt (0), and every form waited for the youngest
+	// loads.  That wait was what bound this kernel.)  The call's ragged last chunk, and every chunk of a batch whose streams do
+	// not start on 16 bytes, is loaded with plain loads by the lanes that split it.
 	const bool dma_ok = (reinterpret_cast<size_t> (a.audio) & 15) == 0 && (a.n_streams == 1 || ((a.stride * C) & 3) == 0);
 	// What lane l of DMA instruction i brings: stereo — frames 4 i + 2 (l >> 5), + 1 of stream l & 31 (both channels); mono —
-	// frames 4 i .. + 3 of stream l.  The sixteen lanes that later read a piece index k of sixteen neighbouring streams find
-	// them 16 bytes apart: conflict-free.  (A stream past the batch re-reads stream s0; its column is zeroed when it is split.)
+	// frames 4 i .. + 3 of stream l.  (A stream past the batch re-reads stream s0; its column is zeroed when it is split.)
+	constexpr int NP = 4;
 	const float* dsrc[NP];
 	{
 		const uint32_t row = C == 2 ? (uint32_t) (lane & 31) : (uint32_t) lane;
@@ -212,367 +226,368 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	const uint32_t stg_lds = (uint32_t) (size_t) (__attribute__ ((address_space (3))) unsigned char*) stg;
 	// (as inline assembly: the compiler must not know that these write LDS — it would wait for them, vmcnt (0), in front of
 	// every LDS access and every barrier that follows, and the point is that they stay in flight across three barriers)
-	auto dma = [&] (int64_t j, int buf) __attribute__ ((always_inline)) {   // whole chunks only: (j + 1) F <= n_frames
+	auto dma = [&] (int64_t j) __attribute__ ((always_inline)) {        // whole chunks only: (j + 1) F <= n_frames; into staging buffer j mod 4
 #pragma unroll
 		for (int i = 0; i < NP; ++i) {
 			const float* const g = dsrc[i] + (size_t) j * (F * C);
-			const uint32_t l = stg_lds + (uint32_t) (buf * NP + i) * 1024u;
+			const uint32_t l = stg_lds + (uint32_t) (((int) (j & (NSTG - 1))) * NP + i) * 1024u;
 			// (m0 is saved and restored inside the statement: the compiler may keep a value of its own there — it does not accept m0 on
 			// a clobber list — and the LDS-DMA reads its LDS base from it)
 			uint32_t m0_was;
 			asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_was) : "v"(g), "s"(l) : "memory");
 		}
 	};
-	auto store = [&] (int i, int slot, float4 v) __attribute__ ((always_inline)) {
-		float* const d = ring + pdst[i] + slot;
-		if (!plive[i]) v = float4{0.f, 0.f, 0.f, 0.f};                   // a row of a stream past the batch (it re-read stream s0)
-		if (C == 2) {                                                    // v = L0 R0 L1 R1
-			*reinterpret_cast<v2f*> (d) = v2f{v.x, v.z};
-			*reinterpret_cast<v2f*> (d + 32 * RSTRIDE) = v2f{v.y, v.w};
-		} else *reinterpret_cast<float4*> (d) = v;
-	};
-	auto fetch_put_ragged = [&] (int64_t j, int slot) __attribute__ ((always_inline)) {   // any chunk, zeros behind the call's last frame
-#pragma unroll 1
-		for (int i = 0; i < NP; ++i) {
-			const int64_t f = j * F + pfr[i];
-			float x[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const int64_t fk = C == 2 ? f + (k >> 1) : f + k;
-				x[k] = fk < n_frames ? prow[i][(size_t) fk * C + (C == 2 ? (k & 1) : 0)] : 0.f;
-			}
-			store (i, slot, float4{x[0], x[1], x[2], x[3]});
-		}
-	};
-
-	// ---- wave 3, lane = column: every sample is split ONCE into the f16 ring, under the column's scale -----------------------
-	ColScale cs;
-	cs.set (238);
-	float hm1 = 0.f, hm2 = 0.f, hm3 = 0.f;                               // max |x| of the three slots in front of the newest one
-	int pend_k = 0;                                                      // this column's older slots still carry a scale 2^-pend_k off
-	auto wave_sync = [] () {                                             // LDS written by other lanes of THIS wave is about to be read
-		__builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_wave_barrier ();
-		__builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup");
-	};
-	auto read_slot = [&] (int pos, float (&x)[F]) {                      // the column's 16 samples at ring position pos (a multiple of 16)
-		const float* const col = ring + lane * RSTRIDE + pos;
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			const float4 v = *reinterpret_cast<const float4*> (col + 4 * q);
-			x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-		}
-	};
-	auto slot_max = [] (const float (&x)[F]) {
-		float m = 0.f;
-#pragma unroll
-		for (int i = 0; i < F; i += 2) m = max3f (m, fabsf (x[i]), fabsf (x[i + 1]));      // (a NaN loses every maximum; an Inf is one)
-		return m;
-	};
-	auto write_slot = [&] (int pos, const float (&x)[F]) {               // ... split under cs.sc into slot pos / 16 of both arrays
-		uint32_t hw[8], lw[8];
-#pragma unroll
-		for (int i = 0; i < 8; ++i) m16::split_pair (x[2 * i] * cs.sc, x[2 * i + 1] * cs.sc, hw[i], lw[i]);
-		unsigned char* const h = ringh + lane * HSTRIDE + 2 * pos;       // 16 samples = 32 bytes
-		unsigned char* const l = ringl + lane * HSTRIDE + 2 * pos;
-		*reinterpret_cast<uint4*> (h)      = uint4{hw[0], hw[1], hw[2], hw[3]};
-		*reinterpret_cast<uint4*> (h + 16) = uint4{hw[4], hw[5], hw[6], hw[7]};
-		*reinterpret_cast<uint4*> (l)      = uint4{lw[0], lw[1], lw[2], lw[3]};
-		*reinterpret_cast<uint4*> (l + 16) = uint4{lw[4], lw[5], lw[6], lw[7]};
-	};
-	// the chunk at ring position pos has landed in the f32 ring: its maximum, the scale check, the split.  If the scale has to
-	// move, the NEW chunk is written under the new scale (nobody reads its slot before the next barrier), the older slots and
-	// un_sh are left to `rescale` at the top of the next iteration — the products of this one are reading them.
-	auto split_regs = [&] (const float (&x)[F], int pos, int next_par) __attribute__ ((always_inline)) {
-		const float m0 = slot_max (x);
-		const float w = max3f (max3f (m0, hm1, hm2), hm3, 0.f);
-		const int se_w = ColScale::se_for (w);
-		const bool move = __float_as_uint (m0) >= cs.cap || (__float_as_uint (w) < cs.low && se_w != cs.se);
-		if (__builtin_expect (__ballot (move) != 0, 0)) {
-			if (move) { pend_k += cs.se - se_w; cs.set (se_w); }           // (every move is served at the next iteration's top: pend_k never adds up)
-			if (lane == 0) flag_sh[next_par] = 1;
-		}
-		write_slot (pos, x);
-		hm3 = hm2; hm2 = hm1; hm1 = m0;
-	};
-	auto split = [&] (int pos, int next_par) __attribute__ ((always_inline)) {      // from the f32 ring (the chunk was stored there piece by piece)
-		float x[F];
-		read_slot (pos, x);
-		split_regs (x, pos, next_par);
-	};
-	// from the staging area the LDS-DMA filled: this column's sixteen samples go to the f32 ring (exact: phase 0) and,
-	// split, to the f16 ring — one trip through the LDS each way
-	auto split_staged = [&] (int buf, int pos, int next_par) __attribute__ ((always_inline)) {
-		float x[F];
-		const unsigned char* const b = stg + buf * (NP * 1024);
+	// this lane's eight samples of chunk j: from the staging buffer the LDS-DMA filled ...
+	auto take_staged = [&]<int CH> (int64_t j, float (&x)[8]) __attribute__ ((always_inline)) {
+		const unsigned char* const b = stg + (int) (j & (NSTG - 1)) * (NP * 1024) + hp * 2048;
 		if (C == 2) {
-			const int r = lane & 31;
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
-				const float4 v = *reinterpret_cast<const float4*> (b + (k >> 1) * 1024 + (r + 32 * (k & 1)) * 16);
-				x[2 * k] = ch ? v.y : v.x; x[2 * k + 1] = ch ? v.w : v.z;
+			for (int k = 0; k < 4; ++k) {                                    // frames 8 hp + 2 k, + 1: instruction 2 hp + (k >> 1), lanes 32 (k & 1) + stream
+				const float4 v = *reinterpret_cast<const float4*> (b + (k >> 1) * 1024 + (32 * (k & 1) + cl) * 16);
+				x[2 * k] = CH ? v.y : v.x; x[2 * k + 1] = CH ? v.w : v.z;
 			}
 		} else {
 #pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				const float4 v = *reinterpret_cast<const float4*> (b + i * 1024 + lane * 16);
+			for (int i = 0; i < 2; ++i) {
+				const float4 v = *reinterpret_cast<const float4*> (b + i * 1024 + scol * 16);
 				x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
 			}
 		}
-		if (!owner) {
+		if (!sowner) {
 #pragma unroll
-			for (int i = 0; i < F; ++i) x[i] = 0.f;
+			for (int i = 0; i < 8; ++i) x[i] = 0.f;
 		}
-		float* const col = ring + lane * RSTRIDE + pos;
-#pragma unroll
-		for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*> (col + 4 * q) = float4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-		split_regs (x, pos, next_par);
 	};
-	// a pending move: the three slots in front of the newest (at ring position pos) times 2^-pend_k, exactly (a power of two;
-	// what falls below f16's range is 2^-27 of the window's new maximum), and the column's un for the products
-	auto rescale = [&] (int pos) {
-		if (pend_k != 0) {
-			const int k = max (-60, min (60, -pend_k));
-			const float r = __uint_as_float ((uint32_t) (127 + k) << 23);
-			typedef _Float16 h2v __attribute__ ((ext_vector_type (2)));
-#pragma unroll 1
-			for (int back = 1; back <= 3; ++back) {
-				int p = pos - 16 * back; p += p < 0 ? RING : 0;
-#pragma unroll 1
-				for (int arr = 0; arr < 2; ++arr) {
-					unsigned char* const b = (arr ? ringl : ringh) + lane * HSTRIDE + 2 * p;
+	// ... or straight from memory (any chunk, zeros behind the call's last frame)
+	auto take_ragged = [&] (int64_t j, float (&x)[8]) __attribute__ ((always_inline)) {
 #pragma unroll
-					for (int i = 0; i < 2; ++i) {
-						uint4 v = *reinterpret_cast<uint4*> (b + 16 * i);
-						uint32_t* const wv = reinterpret_cast<uint32_t*> (&v);
+		for (int i = 0; i < 8; ++i) {
+			const int64_t f = j * F + 8 * hp + i;
+			x[i] = (sowner && f < n_frames) ? srow[(size_t) f * C + sch] : 0.f;
+		}
+	};
+
+	// ---- the split: every sample goes ONCE into the f16 ring, under its column's scale (both lanes of a column keep the same copy of it) ----
+	ColScale cs;
+	cs.set (238);
+	float hm1 = 0.f, hm2 = 0.f, hm3 = 0.f, hm4 = 0.f;                    // max |x| of the four slots in front of the newest one
+	bool pend = false;                                                   // this column's older slots still carry the previous scale
+	auto half_max = [] (const float (&x)[8]) {
+		float m = 0.f;
 #pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							const h2v hv = __builtin_bit_cast (h2v, wv[j]);
-							wv[j] = m16::hi_pair ((float) hv.x * r, (float) hv.y * r);
-						}
-						*reinterpret_cast<uint4*> (b + 16 * i) = v;
-					}
-				}
+		for (int i = 0; i < 8; i += 2) m = max3f (m, fabsf (x[i]), fabsf (x[i + 1]));      // (a NaN loses every maximum; an Inf is one)
+		return m;
+	};
+	auto put_f32 = [&] (int pos, const float (&x)[8]) {                  // exact, for phase 0 and for a later rescale
+		float* const d = ring + scol * RSTRIDE + pos + 8 * hp;
+		*reinterpret_cast<float4*> (d) = float4{x[0], x[1], x[2], x[3]};
+		*reinterpret_cast<float4*> (d + 4) = float4{x[4], x[5], x[6], x[7]};
+	};
+	auto get_f32 = [&] (int pos, float (&x)[8]) {
+		const float* const d = ring + scol * RSTRIDE + pos + 8 * hp;
+		const float4 u = *reinterpret_cast<const float4*> (d), v = *reinterpret_cast<const float4*> (d + 4);
+		x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+	};
+	auto put_f16 = [&] (int pos, const float (&x)[8]) {                  // split under cs.sc into piece 2 (pos / 16) + hp of both arrays
+		uint32_t hw[4], lw[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) m16::split_pair (x[2 * i] * cs.sc, x[2 * i + 1] * cs.sc, hw[i], lw[i]);
+		const int off = scol * HSTRIDE + f16_place ((pos >> 3) + hp, srot);
+		*reinterpret_cast<uint4*> (ringh + off) = uint4{hw[0], hw[1], hw[2], hw[3]};
+		*reinterpret_cast<uint4*> (ringl + off) = uint4{lw[0], lw[1], lw[2], lw[3]};
+	};
+	// The chunk at ring position pos: its maximum, the scale check, both rings.  The scale is made for the maximum of FIVE slots — the
+	// new chunk and the four in front of it: the products read a chunk two iterations after it was split, so the window they read
+	// then reaches four slots back from the chunk split one iteration before.  If the scale has to move, the NEW chunk is written
+	// under the new scale (nobody reads its slot before the next barrier); the older slots and un_sh are left to `rescale` at the top
+	// of the next iteration — the products of this one are reading them.
+	auto split = [&] (const float (&x)[8], int pos, int next_par) __attribute__ ((always_inline)) {
+		const float m0 = max_across_halves (half_max (x));
+		const float w = max3f (max3f (m0, hm1, hm2), hm3, hm4);
+		const int se_w = ColScale::se_for (w);
+		const bool move = __float_as_uint (m0) >= cs.cap || (__float_as_uint (w) < cs.low && se_w != cs.se);
+		if (__builtin_expect (__ballot (move) != 0, 0)) {
+			if (move) { cs.set (se_w); pend = true; }
+			if (lane == 0) flag_sh[next_par] = 1;
+		}
+		put_f32 (pos, x);
+		put_f16 (pos, x);
+		hm4 = hm3; hm3 = hm2; hm2 = hm1; hm1 = m0;
+	};
+	// a pending move: the four slots of the window that starts at ring position w0 are split AGAIN, from the exact samples of the f32
+	// ring, under the new scale (round 4 rescaled the quantised words in place: after a drop of ~100 dB inside one window the older
+	// samples kept 16 bits instead of 22 — ADVICE r4), and the column's un follows for the products
+	auto rescale = [&] (int w0) {
+		if (pend) {
+#pragma unroll 1
+			for (int k = 0; k < 4; ++k) {
+				int p = w0 + 16 * k; p -= p >= RING ? RING : 0;
+				float x[8];
+				get_f32 (p, x);
+				put_f16 (p, x);
 			}
-			un_sh[lane] = cs.un;
-			pend_k = 0;
+			un_sh[scol] = cs.un;
+			pend = false;
 		}
 	};
 
-	const v2f AA = v2f{a1, a2};
-	// ---- the products and the per-frame maps: lane (cc, kg) = column cc of the block, frames 4 kg .. + 3 of the chunk ---------
+	// ---- the products (waves 4 .. 11) and the per-frame maps: lane (cc, kg) = column cc of the block, frames 4 kg .. + 3 of the chunk ----
+	// A block's products run as TWO units on two waves — unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1);
+	// unit B: phases 2 and 3 (12 MFMAs) and the second.
 	const int cc = lane & 15, kg = lane >> 4;
-	m16::AFrag A;
-	const int unit_a = wid == ASET[0] ? 0 : wid == ASET[1] ? 1 : wid == ASET[2] ? 2 : wid == ASET[3] ? 3 : -1;
-	const int unit_b = wid == BSET[0] ? 0 : wid == BSET[1] ? 1 : wid == BSET[2] ? 2 : wid == BSET[3] ? 3 : -1;
-	const int my_block = unit_a >= 0 ? unit_a : unit_b;
-	const bool prod_wave = my_block >= 0;
-	if (prod_wave) {
-		A.load (a.mfma_a, lane);
-		// (used — waited for — right here: a load still pending where the roles part makes the compiler guard every register it
-		// might land in with a vmcnt wait, in EVERY role's loop, and in wave 3's that wait would be for the LDS-DMA in flight)
-#pragma unroll
-		for (int f = 0; f < MTR_M16_FRAGS; ++f) asm volatile ("" : "+v"(A.a[f]));
-	}
-	float pk[2] = { 0.f, 0.f };                                          // raw peak of the values this lane produced (column cc of its block)
-
-	// one of the two units of a block (UB = false: phase 1 + the first pair map; true: phases 2, 3 + the second)
-	auto unit = [&]<bool UB> (int par, int w0, int b, int nfl) __attribute__ ((always_inline)) {
-		int q0 = (w0 >> 3) + kg; q0 -= q0 >= 10 ? 10 : 0;
-		int q1 = q0 + 4; q1 -= q1 >= 10 ? 10 : 0;
-		const int col = 16 * b + cc;
-		const unsigned char* const h = ringh + col * HSTRIDE;
-		const unsigned char* const l = ringl + col * HSTRIDE;
-		m16::BFrag B;
-		B.h0 = *reinterpret_cast<const uint4*> (h + 16 * q0);
-		B.h1 = *reinterpret_cast<const uint4*> (h + 16 * q1);
-		B.l0 = *reinterpret_cast<const uint4*> (l + 16 * q0);
-		B.l1 = *reinterpret_cast<const uint4*> (l + 16 * q1);
-		float4 x0 = float4{0.f, 0.f, 0.f, 0.f};
-		if (!UB) { int o0 = w0 + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0; x0 = *reinterpret_cast<const float4*> (ring + col * RSTRIDE + o0); }
-		const float un = un_sh[col];
-		constexpr int P0 = UB ? 1 : 0, NPH = UB ? 2 : 1;
-		m16::f4 y[NPH];
+	const int blk = (wid - 4) & 3;
+	const int ucol = 16 * blk + cc;
+	const int urot = f16_rot (ucol);
+	const bool prod_wave = wid >= 4;
+	float pk = 0.f;                                                      // raw peak of the values this lane produced (column cc of its block)
+	// the operands of a chunk: read from the rings one iteration AHEAD of the products, behind the MFMAs of the chunk before and
+	// under its maps (round 4 read them at the top of the iteration they were used in: ~200 cycles of LDS latency per chunk on
+	// every unit's critical path)
+	struct Ops { m16::BFrag B; float4 x0; float un; };
+	Ops ops[2];
+	auto fetch_ops = [&]<bool UB> (Ops& o, int sw) __attribute__ ((always_inline)) {   // sw = the window's first slot = chunk index mod 6
+		// window positions 32 st + 8 kg .. + 7 = piece (2 sw + 4 st + kg) mod 12 of the column
+		int q0 = 2 * sw + kg; q0 -= q0 >= 2 * NSLOT ? 2 * NSLOT : 0;
+		int q1 = q0 + 4; q1 -= q1 >= 2 * NSLOT ? 2 * NSLOT : 0;
+		const int p0 = ucol * HSTRIDE + f16_place (q0, urot), p1 = ucol * HSTRIDE + f16_place (q1, urot);
+		o.B.h0 = *reinterpret_cast<const uint4*> (ringh + p0);
+		o.B.h1 = *reinterpret_cast<const uint4*> (ringh + p1);
+		o.B.l0 = *reinterpret_cast<const uint4*> (ringl + p0);
+		o.B.l1 = *reinterpret_cast<const uint4*> (ringl + p1);
+		o.x0 = float4{0.f, 0.f, 0.f, 0.f};
+		if (!UB) { int o0 = 16 * sw + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0; o.x0 = *reinterpret_cast<const float4*> (ring + ucol * RSTRIDE + o0); }
+		o.un = un_sh[ucol];
+	};
+	// one of the two units of a block (UB = false: phase 1 + the first pair map; true: phases 2, 3 + the second): the MFMAs ...
+	// (af = the unit's own tap fragments: [phase of the unit][window step][hi | lo], four of the table's twelve for unit A, eight for B)
+	auto unit_mfma = [&]<bool UB> (const m16::h8* af, const Ops& o, m16::f4 (&y)[2]) __attribute__ ((always_inline)) {
+		constexpr int NPH = UB ? 2 : 1;
 #pragma unroll
 		for (int p = 0; p < NPH; ++p) y[p] = m16::f4{0.f, 0.f, 0.f, 0.f};
 		// (the order of m16::block: consecutive MFMAs write different accumulators where there are two)
 #pragma unroll
-		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 0) * 2 + 0], B.h0, y[p]);
+		for (int p = 0; p < NPH; ++p) M16_MFMA (af[(p * 2 + 0) * 2 + 0], o.B.h0, y[p]);
 #pragma unroll
-		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 1) * 2 + 0], B.h1, y[p]);
+		for (int p = 0; p < NPH; ++p) M16_MFMA (af[(p * 2 + 1) * 2 + 0], o.B.h1, y[p]);
 #pragma unroll
-		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 0) * 2 + 0], B.l0, y[p]);
+		for (int p = 0; p < NPH; ++p) M16_MFMA (af[(p * 2 + 0) * 2 + 0], o.B.l0, y[p]);
 #pragma unroll
-		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 1) * 2 + 0], B.l1, y[p]);
+		for (int p = 0; p < NPH; ++p) M16_MFMA (af[(p * 2 + 1) * 2 + 0], o.B.l1, y[p]);
 #pragma unroll
-		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 0) * 2 + 1], B.h0, y[p]);
+		for (int p = 0; p < NPH; ++p) M16_MFMA (af[(p * 2 + 0) * 2 + 1], o.B.h0, y[p]);
 #pragma unroll
-		for (int p = 0; p < NPH; ++p) M16_MFMA (A.a[((P0 + p) * 2 + 1) * 2 + 1], B.h1, y[p]);
+		for (int p = 0; p < NPH; ++p) M16_MFMA (af[(p * 2 + 1) * 2 + 1], o.B.h1, y[p]);
+	};
+	// ... and the maps: two attacks in a row are z <- max (z, a z + max (b1, b2), a^2 z + (a b1 + b2)), b = w v — two intercepts per
+	// pair and filter, written straight to where that filter's chain lane reads them as ONE 8-byte word: row [half][frame], then
+	// [group of 16 columns][filter][column] (the unit's sixteen lanes of a frame store 128 contiguous bytes per filter; a chain wave's
+	// 32-lane read groups — sixteen columns x two filters — read 256)
+	auto unit_maps = [&]<bool UB> (int par, const float4& x0, float un, const m16::f4 (&y)[2], int nfl) __attribute__ ((always_inline)) {
+		constexpr int NPH = UB ? 2 : 1;
 		const float xr[4] = { x0.x, x0.y, x0.z, x0.w };
 		const v2f W = v2f{a.w1, a.w2};
 		float pm = 0.f, px = 0.f;
+		unsigned char* const row = cbuf + par * CBUF_B + ((UB ? F : 0) + 4 * kg) * CROW + blk * 256 + cc * 8;
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const float keep = r < nfl ? 1.f : 0.f;
-			unsigned char* const cd = cbuf + par * CBUF_B + (((4 * kg + r) * 2 + (UB ? 1 : 0)) * NCOL + col) * 16;
+			unsigned char* const cd = row + r * CROW;
+			v2f g1, g2;
 			if (!UB) {
 				px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
 				pm = __builtin_fmaxf (pm, fabsf (y[0][r]) * keep);
 				const v2f b1 = W * fabsf (xr[r]), b2 = W * (fabsf (y[0][r]) * un);
-				const v2f d1 = max2 (b1, b2), d2 = fma2 (AA, b1, b2);
-				*reinterpret_cast<float4*> (cd) = float4{d1.x, d1.y, d2.x, d2.y};
+				g1 = max2 (b1, b2); g2 = v2f{__builtin_fmaf (AA.x, b1.x, b2.x), __builtin_fmaf (AA.y, b1.y, b2.y)};
 			} else {
 				pm = __builtin_fmaxf (pm, __builtin_fmaxf (fabsf (y[0][r]), fabsf (y[NPH - 1][r])) * keep);
 				const v2f b3 = W * (fabsf (y[0][r]) * un), b4 = W * (fabsf (y[NPH - 1][r]) * un);
-				const v2f e1 = max2 (b3, b4), e2 = fma2 (AA, b3, b4);
-				*reinterpret_cast<float4*> (cd) = float4{e1.x, e1.y, e2.x, e2.y};
+				g1 = max2 (b3, b4); g2 = v2f{__builtin_fmaf (AA.x, b3.x, b4.x), __builtin_fmaf (AA.y, b3.y, b4.y)};
 			}
+			*reinterpret_cast<v2f*> (cd) = v2f{g1.x, g2.x};                   // filter 1: (c, c')
+			*reinterpret_cast<v2f*> (cd + 128) = v2f{g1.y, g2.y};             // filter 2
 		}
-		pk[0] = max3f (pk[0], px, pm * un);
+		pk = max3f (pk, px, pm * un);
 	};
 
-	// ---- prologue: the 48 frames before the call (47 of history; frame -48 is never multiplied by a non-zero tap) and chunk 0 ----
-	if (wid != 0) {
-		for (int e = (wid - 1) * 64 + lane; e < NCOL * 48; e += (NW - 1) * 64) {
-			const int col = e / 48, i = e % 48;                              // frame i - 48 -> ring position 32 + i
-			const uint32_t s = s0 + (uint32_t) (C == 2 ? (col & 31) : col);
-			float x = 0.f;
-			if (s < a.n_streams && i >= 1)                                   // history rows are [frame][2], right channel zero for mono engines
-				x = a.hist[((size_t) s * MTR_FIR_HALO + (size_t) (i - 1)) * 2 + (C == 2 ? (col >> 5) : 0)];
-			ring[col * RSTRIDE + 32 + i] = x;
-		}
-		if (wid == 3) fetch_put_ragged (0, 0);
+	// ---- prologue: the 48 frames before the call (47 of history; frame -48 is never multiplied by a non-zero tap), chunks 0 and 1 ----
+	for (int e = threadIdx.x; e < NCOL * 48; e += NTHREADS) {
+		const int col = e / 48, i = e % 48;                                  // frame i - 48 -> ring position i
+		const uint32_t s = s0 + (uint32_t) (C == 2 ? (col & 31) : col);
+		float x = 0.f;
+		if (s < a.n_streams && i >= 1)                                       // history rows are [frame][2], right channel zero for mono engines
+			x = a.hist[((size_t) s * MTR_FIR_HALO + (size_t) (i - 1)) * 2 + (C == 2 ? (col >> 5) : 0)];
+		ring[col * RSTRIDE + i] = x;
 	}
 	if (threadIdx.x < 2) flag_sh[threadIdx.x] = 0;
+	float xc0[8], xc1[8];
+	if (wid == 2 || wid == 3) { take_ragged (0, xc0); take_ragged (1, xc1); }
 	__syncthreads ();
-	if (wid == 3) {
-		// the first window: one scale for its four slots, from their common maximum
-		float x[4][F];
-		read_slot (32, x[0]); read_slot (48, x[1]); read_slot (64, x[2]); read_slot (0, x[3]);
-		hm3 = slot_max (x[0]); hm2 = slot_max (x[1]); hm1 = slot_max (x[2]);
-		const float m0 = slot_max (x[3]);
-		cs.set (ColScale::se_for (max3f (max3f (m0, hm1, hm2), hm3, 0.f)));
-		write_slot (32, x[0]); write_slot (48, x[1]); write_slot (64, x[2]); write_slot (0, x[3]);
-		un_sh[lane] = cs.un;
-		hm3 = hm2; hm2 = hm1; hm1 = m0;
-		if (dma_ok && !MTR_TPB_DBG_NOFETCH) {                           // chunks 1 and 2: on their way before the loop starts
-			if (2 * F <= n_frames) dma (1, 1);
-			if (3 * F <= n_frames) dma (2, 2);
+	if (wid == 2 || wid == 3) {
+		// the first window and the chunk behind it: one scale for the five slots, from their common maximum
+		float xh[3][8];
+		get_f32 (0, xh[0]); get_f32 (16, xh[1]); get_f32 (32, xh[2]);
+		hm4 = max_across_halves (half_max (xh[0])); hm3 = max_across_halves (half_max (xh[1])); hm2 = max_across_halves (half_max (xh[2]));
+		hm1 = max_across_halves (half_max (xc0));
+		const float m0 = max_across_halves (half_max (xc1));
+		cs.set (ColScale::se_for (max3f (max3f (m0, hm1, hm2), hm3, hm4)));
+		put_f16 (0, xh[0]); put_f16 (16, xh[1]); put_f16 (32, xh[2]);
+		put_f32 (48, xc0); put_f16 (48, xc0);
+		put_f32 (64, xc1); put_f16 (64, xc1);
+		un_sh[scol] = cs.un;
+		hm4 = hm3; hm3 = hm2; hm2 = hm1; hm1 = m0;
+		if (wid == 2 && dma_ok && !MTR_TPB_DBG_NOFETCH && !MTR_TPB_DBG_NODMA) {   // chunks 2, 3 and 4: on their way before the loop starts,
+			int sent = 0;                                                  // and chunk 2 has landed behind the barrier below
+			if (3 * F <= n_frames) { dma (2); ++sent; }
+			if (4 * F <= n_frames) { dma (3); ++sent; }
+			if (5 * F <= n_frames) { dma (4); ++sent; }
+			if (sent == 3)      asm volatile ("s_waitcnt vmcnt(8)" ::: "memory");
+			else if (sent == 2) asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
+			else                asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 	}
 	__syncthreads ();
 
-	// iteration t: chunk t + 1 is fetched and split, chunk t goes through the products, chunk t - 1 through the maps, chunk t - 2 through the chains
+	// iteration t: chunk t + 5 leaves HBM, chunk t + 2 is split, chunk t goes through the products (whose operands were read an
+	// iteration ago) and the maps, chunk t - 1 through the chains
 #ifdef MTR_TPB_PROF
 	unsigned long long pr[4] = { 0, 0, 0, 0 };
 #endif
-	// one frame of the chains: z <- max (w3 z, a w3 z + c1, ..., a^4 w3 z + c4) for both filters (packed), then m
-	v2f zz = v2f{z1, z2};
-	v2f sl2[5];
-#pragma unroll
-	for (int k = 0; k < 5; ++k) sl2[k] = v2f{s1[k], s2[k]};
-	const v2f AA2 = v2f{(float) ((double) a1 * (double) a1), (float) ((double) a2 * (double) a2)};   // (the second pair's slopes are a, a^2)
+	// one frame of a chain: z <- max (w3 z, a w3 z + c1, a^2 w3 z + c2), then z <- max (z, a z + c3, a^2 z + c4); m = max (m, z1 + z2)
+	// (the other filter's state sits in the neighbouring lane: one DPP add)
 	auto chain = [&]<bool FULL> (int par, int nf) {
-		const unsigned char* const src = cbuf + par * CBUF_B + lane * 16;
-		float4 q1[F], q2[F];                                             // the maps do not depend on the state: all sixteen frames' reads go out first
+		const unsigned char* const src = cbuf + par * CBUF_B + (2 * hw_ + (ci >> 4)) * 256 + phi * 128 + (ci & 15) * 8;
+		v2f q1[F], q2[F];                                                // the maps do not depend on the state: all sixteen frames' reads go out first
 #pragma unroll
 		for (int f = 0; f < F; ++f) {
-			q1[f] = *reinterpret_cast<const float4*> (src + (f * 2 + 0) * NCOL * 16);
-			q2[f] = *reinterpret_cast<const float4*> (src + (f * 2 + 1) * NCOL * 16);
+			q1[f] = *reinterpret_cast<const v2f*> (src + f * CROW);
+			q2[f] = *reinterpret_cast<const v2f*> (src + (F + f) * CROW);
 		}
 #pragma unroll
 		for (int f = 0; f < F; ++f) {
 			if (FULL || f < nf) {                                            // wave-uniform: only the call's last chunk is short
-				const v2f u0 = sl2[0] * zz, u1 = fma2 (sl2[1], zz, v2f{q1[f].x, q1[f].y}), u2 = fma2 (sl2[2], zz, v2f{q1[f].z, q1[f].w});
-				const v2f zh = v2f{max3f (u0.x, u1.x, u2.x), max3f (u0.y, u1.y, u2.y)};
-				const v2f w1_ = fma2 (AA, zh, v2f{q2[f].x, q2[f].y}), w2_ = fma2 (AA2, zh, v2f{q2[f].z, q2[f].w});
-				zz = v2f{max3f (zh.x, w1_.x, w2_.x), max3f (zh.y, w1_.y, w2_.y)};
-				zm = __builtin_fmaxf (zm, zz.x + zz.y);
+				const float u0 = sl0 * z, u1 = __builtin_fmaf (sl1, z, q1[f].x), u2 = __builtin_fmaf (sl2_, z, q1[f].y);
+				const float zh = max3f (u0, u1, u2);
+				const float v1 = __builtin_fmaf (ap, zh, q2[f].x), v2 = __builtin_fmaf (ap2, zh, q2[f].y);
+				z = max3f (zh, v1, v2);
+				const float zo = __uint_as_float (__builtin_amdgcn_update_dpp (0, __float_as_uint (z), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+				zm = __builtin_fmaxf (zm, z + zo);                            // z1 + z2 (the same bits in both lanes)
 			}
 		}
 	};
-	constexpr int LAG = 1;                                               // chunks between the products and the chains
 	// THE LOOP, once per role: every wave runs the same iterations and the same barriers, but each role's copy of the loop has
 	// its own registers (in ONE loop with the roles as branches the compiler re-fetched the products' twelve tap fragments from
-	// global memory in every iteration — the chains' thirty-two map registers were live across the same loop — and a block of
-	// products took 800 cycles, more than half of them waiting for those loads).
-	int slot_w = 32, slot_p = F % RING;                                  // window start of chunk t; where chunk t + 1 goes
-	const int64_t n_it = n_chunks + LAG;
+	// global memory in every iteration).
+	int sw = 0;                                                          // chunk t mod 6: the first slot of its window, and its pieces' base
+	const int64_t n_it = n_chunks + 1;
 	// iterations [t0, t1) of the loop (the parity of an iteration is a compile-time constant in `work`: the buffers it selects)
 	auto run_range = [&]<bool SPLITTER> (int64_t t0, int64_t t1, auto&& work) __attribute__ ((always_inline)) {
 		auto iteration = [&]<int PAR> (int64_t t) __attribute__ ((always_inline)) {
-			// a column's scale moved when chunk t was split (last iteration): its older slots and its un follow now, before this
-			// iteration's products read them — the cold path, with its own barrier (the flag is uniform: every wave reads it here,
-			// and wave 3 clears it only behind that barrier)
-			const int moved = __builtin_amdgcn_readfirstlane (flag_sh[PAR]);
-			if (__builtin_expect (moved != 0, 0)) {
-				if constexpr (SPLITTER) rescale (slot_w + 48 >= RING ? slot_w + 48 - RING : slot_w + 48);   // chunk t's own slot = the window's last
-				__syncthreads ();
-				if (SPLITTER && lane == 0) flag_sh[PAR] = 0;
-			}
+			// A column's scale moved when chunk t + 1 was split (last iteration): the window of chunk t — read by this iteration's
+			// products, and three of its slots by the next one's — is split again and its un follows, in a cold path with its own
+			// barrier.  The flag is uniform; its read goes out HERE and is waited for where the role needs the answer — behind the
+			// chains' frames, behind the products' MFMAs (which run on what was read ahead and are run again if that was stale), with
+			// the split's own data — instead of an LDS round trip at the top of every iteration of every wave.  Every role asks once
+			// and, if the answer is yes, passes the cold barrier once; the split clears the flag behind it.
+			const int flag = flag_sh[PAR];
+			auto moved = [&] () __attribute__ ((always_inline)) { return __builtin_expect (__builtin_amdgcn_readfirstlane (flag) != 0, 0); };
 			PROF_NOW (c0_);
-			work.template operator()<PAR> (t, slot_w, slot_p);
+			work.template operator()<PAR> (t, moved);
 			PROF_NOW (c1_);
 			__syncthreads ();
 			PROF_NOW (c2_);
 			PROF_ADD (0, c1_ - c0_); PROF_ADD (2, c2_ - c1_); PROF_ADD (3, c2_ - c0_);
-			slot_w = slot_w + F >= RING ? slot_w + F - RING : slot_w + F;
-			slot_p = slot_p + F >= RING ? slot_p + F - RING : slot_p + F;
+			sw = sw + 1 >= NSLOT ? 0 : sw + 1;
 		};
-		for (int64_t t = t0; t < t1; ++t) {
-			if (t & 1) iteration.template operator()<1> (t);
-			else       iteration.template operator()<0> (t);
+		// (in pairs: what an even iteration reads ahead for the odd one behind it — the products' operands — stays in the registers it
+		// was loaded into; with one iteration per trip and the parity as a branch the compiler rotated ~40 registers per trip)
+		int64_t t = t0;
+		if (t < t1 && (t & 1)) { iteration.template operator()<1> (t); ++t; }
+		for (; t + 1 < t1; t += 2) {
+			iteration.template operator()<0> (t);
+			iteration.template operator()<1> (t + 1);
 		}
+		if (t < t1) iteration.template operator()<0> (t);
 	};
 	auto run = [&]<bool SPLITTER> (auto&& work) __attribute__ ((always_inline)) { run_range.template operator()<SPLITTER> (0, n_it, work); };
-	if (wid == 0) {
-		run.template operator()<false> ([&]<int PAR> (int64_t t, int, int) __attribute__ ((always_inline)) {
-			if (t >= LAG && !MTR_TPB_DBG_NOCHAIN) {
-				const int64_t left = n_frames - (t - LAG) * F;
-				if (left >= F) chain.template operator()<true> (PAR ^ (LAG & 1), F);
-				else chain.template operator()<false> (PAR ^ (LAG & 1), (int) left);
+	if (wid < 2) {
+		run.template operator()<false> ([&]<int PAR> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+			if (t >= 1 && !MTR_TPB_DBG_NOCHAIN) {
+				const int64_t left = n_frames - (t - 1) * F;
+				if (left >= F) chain.template operator()<true> (PAR ^ 1, F);
+				else chain.template operator()<false> (PAR ^ 1, (int) left);
 			}
+			if (moved ()) __syncthreads ();
 		});
-	} else if (wid == 3) {
+	} else if (wid < 4) {
 		// Two loops.  The first serves the whole chunks that came by LDS-DMA, and holds NO vector-memory instruction the compiler
 		// knows of: any such load makes it count vmcnt, and its conservative waits (vmcnt (0) where paths join) would wait for the
-		// DMA in flight as well.  The second takes over where chunk t + 1 is the call's ragged last one (or for the whole call,
+		// DMA in flight as well.  The second takes over where chunk t + 2 is the call's ragged last one (or for the whole call,
 		// when the streams do not start on 16 bytes) and drains the pipeline.
 		const int64_t n_whole = n_frames / F;
-		const int64_t t_dma = dma_ok && !MTR_TPB_DBG_NOFETCH ? (n_whole > 1 ? n_whole - 1 : 0) : 0;     // chunks 1 .. n_whole - 1 are staged
-		run_range.template operator()<true> (0, t_dma, [&]<int PAR> (int64_t t, int, int slot_p) __attribute__ ((always_inline)) {
-			// chunk t + 3 leaves HBM; chunk t + 1, sent three iterations ago, is split from the staging area into both rings
-			const int sb1 = (int) ((t + 1) % 3);
-			if ((t + 4) * F <= n_frames && !MTR_TPB_DBG_NODMA) dma (t + 3, sb1 == 0 ? 2 : sb1 - 1);   // (t + 3) % 3: the slot chunk t was read from, an iteration ago
-			// chunk t + 1 has landed when at most the DMA instructions of the younger chunks are outstanding
-			const int younger = ((t + 3) * F <= n_frames ? 1 : 0) + ((t + 4) * F <= n_frames ? 1 : 0);
-			if (MTR_TPB_DBG_NODMA) { }
-			else if (younger == 2) asm volatile ("s_waitcnt vmcnt(8)" ::: "memory");
-			else if (younger == 1) asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
-			else                   asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-			if (!MTR_TPB_DBG_NOSPLIT) split_staged (sb1, slot_p, PAR ^ 1);
-		});
-		run_range.template operator()<true> (t_dma, n_it, [&]<int PAR> (int64_t t, int, int slot_p) __attribute__ ((always_inline)) {
-			if (t + 1 < n_chunks && !MTR_TPB_DBG_NOFETCH) {
-				fetch_put_ragged (t + 1, slot_p);
-				wave_sync ();
-				split (slot_p, PAR ^ 1);
-			}
-		});
-	} else {
-		auto run_unit = [&]<bool UB> (int b) __attribute__ ((always_inline)) {
-			run.template operator()<false> ([&]<int PAR> (int64_t t, int slot_w, int) __attribute__ ((always_inline)) {
-				if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
-					const int64_t left = n_frames - t * F - 4 * kg;             // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
-					unit.template operator()<UB> (PAR, slot_w, b, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
+		const int64_t t_dma = dma_ok && !MTR_TPB_DBG_NOFETCH ? (n_whole > 2 ? n_whole - 2 : 0) : 0;     // chunks 2 .. n_whole - 1 are staged
+		auto staged = [&]<int CH, bool SENDER> () __attribute__ ((always_inline)) {
+			run_range.template operator()<true> (0, t_dma, [&]<int PAR> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+				// chunk t + 5 leaves HBM (into the staging buffer chunk t + 1 was read from, an iteration ago)
+				if (SENDER && (t + 6) * F <= n_frames && !MTR_TPB_DBG_NODMA) dma (t + 5);
+				float x[8];
+				take_staged.template operator()<CH> (t + 2, x);
+				if (moved ()) { rescale (16 * sw); __syncthreads (); if (lane == 0) flag_sh[PAR] = 0; }
+				if (!MTR_TPB_DBG_NOSPLIT) {
+					int sp = sw + 5; sp -= sp >= NSLOT ? NSLOT : 0;              // chunk t + 2's slot
+					split (x, 16 * sp, PAR ^ 1);
+				}
+				// chunk t + 3 — the next iteration's — has landed when at most the DMA instructions of the younger chunks are outstanding;
+				// the wait stands in front of the barrier that lets BOTH split waves read it
+				if (SENDER && !MTR_TPB_DBG_NODMA) {
+					const int younger = ((t + 5) * F <= n_frames ? 1 : 0) + ((t + 6) * F <= n_frames ? 1 : 0);
+					if (younger == 2)      asm volatile ("s_waitcnt vmcnt(8)" ::: "memory");
+					else if (younger == 1) asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
+					else                   asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 				}
 			});
 		};
-		if (unit_a >= 0) run_unit.template operator()<false> (unit_a);
-		else if (unit_b >= 0) run_unit.template operator()<true> (unit_b);
-		else run.template operator()<false> ([&]<int PAR> (int64_t, int, int) __attribute__ ((always_inline)) { });   // (idle: keeps the barriers' count)
+		if (wid == 2) staged.template operator()<0, true> ();
+		else          staged.template operator()<C == 2 ? 1 : 0, false> ();
+		run_range.template operator()<true> (t_dma, n_it, [&]<int PAR> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+			if (moved ()) { rescale (16 * sw); __syncthreads (); if (lane == 0) flag_sh[PAR] = 0; }
+			if (t + 2 < n_chunks && !MTR_TPB_DBG_NOFETCH) {
+				float x[8];
+				take_ragged (t + 2, x);
+				int sp = sw + 5; sp -= sp >= NSLOT ? NSLOT : 0;
+				split (x, 16 * sp, PAR ^ 1);
+			}
+		});
+	} else {
+		auto run_unit = [&]<bool UB> () __attribute__ ((always_inline)) {
+			constexpr int NF = UB ? 8 : 4, F0 = UB ? 4 : 0;
+			m16::h8 af[NF];
+#pragma unroll
+			for (int f = 0; f < NF; ++f) af[f] = *reinterpret_cast<const m16::h8*> (a.mfma_a + (F0 + f) * 512 + lane * 8);
+			// (used — waited for — right here: a load still pending in front of the loop makes the compiler guard every register it
+			// might land in with a vmcnt wait inside it)
+#pragma unroll
+			for (int f = 0; f < NF; ++f) asm volatile ("" : "+v"(af[f]));
+			fetch_ops.template operator()<UB> (ops[0], 0);                  // the first chunk's operands
+			run.template operator()<false> ([&]<int PAR> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+				if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
+					m16::f4 y[2];
+					unit_mfma.template operator()<UB> (af, ops[PAR], y);         // on the operands read an iteration ago ...
+					if (moved ()) {                                                // ... which are stale if the window has just been split again
+						__syncthreads ();
+						fetch_ops.template operator()<UB> (ops[PAR], sw);
+						unit_mfma.template operator()<UB> (af, ops[PAR], y);
+					}
+					// the next chunk's operands, unconditionally (behind the call's last chunk they are whatever the ring holds: nobody uses
+					// them, and a branch here would put a wait for them in front of the maps)
+					fetch_ops.template operator()<UB> (ops[PAR ^ 1], sw + 1 >= NSLOT ? 0 : sw + 1);
+					const int64_t left = n_frames - t * F - 4 * kg;             // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
+					unit_maps.template operator()<UB> (PAR, ops[PAR].x0, ops[PAR].un, y, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
+				} else if (moved ()) __syncthreads ();
+			});
+		};
+		if (wid < 8) run_unit.template operator()<false> ();
+		else         run_unit.template operator()<true> ();
 	}
-	z1 = zz.x; z2 = zz.y;
 #ifdef MTR_TPB_PROF
 	if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 4; ++i) g_tpb_prof[wid][i] = pr[i];
 #endif
@@ -581,14 +596,16 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	uint32_t* const pk_sh = reinterpret_cast<uint32_t*> (ring);          // the ring is spent
 	if (wid == 0) pk_sh[lane] = 0u;
 	__syncthreads ();
-	if (prod_wave) atomicMax (&pk_sh[16 * my_block + cc], __float_as_uint (pk[0]));
+	if (prod_wave) atomicMax (&pk_sh[ucol], __float_as_uint (pk));
 	__syncthreads ();
-	if (wid == 0 && owner) {
-		st->tpb_z1[ch] = z1 + 1e-20f;                                    // truepeakdsp.cc:86-87
-		st->tpb_z2[ch] = z2 + 1e-20f;
-		st->tpb_m[ch] = zm * a.g;                                        // :89, then read (m, p)
-		st->tpb_p[ch] = __uint_as_float (pk_sh[lane]);
-		if (C == 1) { st->tpb_z1[1] = 1e-20f; st->tpb_z2[1] = 1e-20f; st->tpb_m[1] = 0.f; st->tpb_p[1] = 0.f; }   // mono engines keep a zero right channel
+	if (wid < 2 && cowner) {
+		if (phi) cst->tpb_z2[cch] = z + 1e-20f;                            // truepeakdsp.cc:86-87
+		else {
+			cst->tpb_z1[cch] = z + 1e-20f;
+			cst->tpb_m[cch] = zm * a.g;                                      // :89, then read (m, p)
+			cst->tpb_p[cch] = __uint_as_float (pk_sh[ccol]);
+			if (C == 1) { cst->tpb_z1[1] = 1e-20f; cst->tpb_z2[1] = 1e-20f; cst->tpb_m[1] = 0.f; cst->tpb_p[1] = 0.f; }   // mono engines keep a zero right channel
+		}
 	}
 }
 

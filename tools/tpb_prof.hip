@@ -1,6 +1,7 @@
 // tools/tpb_prof.hip — where does a chunk of k_tpb go?  Builds the kernel with cycle counters per wave
 // (work / barrier wait / total) and prints them for workgroup 0.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imeters.lv2_amd/csrc tools/tpb_prof.hip -o tools/tpb_prof
+// Build: tools/build_tpb_prof.sh (the default build and the elimination builds: a role switched off, -DMTR_TIMING_ONLY_BUILD — wrong
+// results by construction, timing only)
 #define MTR_TPB_PROF 1
 #include "../meters.lv2_amd/csrc/mtr_tpb.hip"
 
@@ -42,10 +43,10 @@ int main (int argc, char** argv)
 	float ms; hipEventElapsedTime (&ms, e0, e1);
 	unsigned long long pr[12][4];
 	hipMemcpyFromSymbol (pr, HIP_SYMBOL (g_tpb_prof), sizeof pr);
-	const double nchunk = (double) ((T + F - 1) / F + 2);
+	const double nchunk = (double) ((T + F - 1) / F + 1);
 	printf ("stride %llu frames (= 128 B x %.3f): ", (unsigned long long) ST, ST * 8 / 128.0);
 	printf ("S=%u T=%llu: %.3f ms, %.0f ns per chunk of %d frames\n", S, (unsigned long long) T, ms, ms * 1e6 / nchunk, F);
-	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (default build — wave 0: the chains; 3: LDS-DMA + split; 1, 5, 2, 6: unit B of blocks 0 .. 3 (phases 2, 3 + second pair map); 4, 9, 10, 7: unit A (phase 1 + first pair map); 8, 11 idle)\n");
+	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2: LDS-DMA + split of columns 0 .. 31; 3: split of 32 .. 63; 4 .. 7: unit A of blocks 0 .. 3 (phase 1 + first pair map); 8 .. 11: unit B (phases 2, 3 + second pair map); waves w, w + 4, w + 8 share a SIMD)\n");
 	for (int w = 0; w < NW; ++w) printf ("  %2d  %7.1f  %7.1f  %7.1f\n", w, pr[w][0] / nchunk, pr[w][2] / nchunk, pr[w][3] / nchunk);
 	return 0;
 }
