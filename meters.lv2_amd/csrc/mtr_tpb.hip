@@ -107,7 +107,7 @@ constexpr int HSTRIDE = 256;                   // bytes per column and array of 
                                                // as four pair words each), piece q at place (q + rot (column)) mod 16 — see f16_rot
 constexpr int HRING_B = NCOL * HSTRIDE;        // one array: hi | lo
 constexpr int AUX_B = 512;                     // float un [NCOL]; int flag [2]
-constexpr int CROW = 1024;                     // a chunk of maps: [half][frame] rows of [group of 16 columns][filter][column] x (c, c') = 8 bytes
+constexpr int CROW = 1024;                     // a chunk of maps: [half][frame] rows of [group of 8 columns][filter][column] x (c, c') = 8 bytes
 constexpr int CBUF_B = 2 * F * CROW;
 constexpr int NSTG = 4;                        // chunks on their way from HBM, as the LDS-DMA leaves them: [chunk % 4][piece 64 i + lane] x 16 bytes
 constexpr int STG_B = NSTG * 4 * 1024;
@@ -130,6 +130,9 @@ __device__ __forceinline__ int f16_place (int q, int rot) { return ((q + rot) & 
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
 __device__ __forceinline__ v2f max2 (v2f a, v2f b) { return v2f{__builtin_fmaxf (a.x, b.x), __builtin_fmaxf (a.y, b.y)}; }
+// max (m, a, b) of values that are already non-negative results of VALU arithmetic: one v_max3_f32 (as a C expression every operand
+// that is not provably quiet costs a canonicalising v_max (x, x) first)
+__device__ __forceinline__ float max3_plain (float m, float a, float b) { float r; asm ("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
 // the maximum of a value over lanes l and l ^ 32, in both (v_permlane32_swap: the upper half of one operand against the lower of the other)
 __device__ __forceinline__ float max_across_halves (float m)
 {
@@ -227,15 +230,19 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// (as inline assembly: the compiler must not know that these write LDS — it would wait for them, vmcnt (0), in front of
 	// every LDS access and every barrier that follows, and the point is that they stay in flight across three barriers)
 	auto dma = [&] (int64_t j) __attribute__ ((always_inline)) {        // whole chunks only: (j + 1) F <= n_frames; into staging buffer j mod 4
-#pragma unroll
-		for (int i = 0; i < NP; ++i) {
-			const float* const g = dsrc[i] + (size_t) j * (F * C);
-			const uint32_t l = stg_lds + (uint32_t) (((int) (j & (NSTG - 1))) * NP + i) * 1024u;
-			// (m0 is saved and restored inside the statement: the compiler may keep a value of its own there — it does not accept m0 on
-			// a clobber list — and the LDS-DMA reads its LDS base from it)
-			uint32_t m0_was;
-			asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_was) : "v"(g), "s"(l) : "memory");
-		}
+		const float* const g0 = dsrc[0] + (size_t) j * (F * C);
+		const float* const g1 = dsrc[1] + (size_t) j * (F * C);
+		const float* const g2 = dsrc[2] + (size_t) j * (F * C);
+		const float* const g3 = dsrc[3] + (size_t) j * (F * C);
+		const uint32_t l = stg_lds + (uint32_t) ((int) (j & (NSTG - 1)) * NP) * 1024u;
+		// (m0 — the LDS base of an LDS-DMA — is saved and restored inside the statement: the compiler may keep a value of its own
+		// there, and does not accept m0 on a clobber list; an s_nop between a write of m0 and the instruction that reads it)
+		uint32_t m0_was;
+		asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+		              "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+		              "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+		              "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+		              : "=&s"(m0_was) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(l) : "memory", "scc");
 	};
 	// this lane's eight samples of chunk j: from the staging buffer the LDS-DMA filled ...
 	auto take_staged = [&]<int CH> (int64_t j, float (&x)[8]) __attribute__ ((always_inline)) {
@@ -243,7 +250,11 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		if (C == 2) {
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {                                    // frames 8 hp + 2 k, + 1: instruction 2 hp + (k >> 1), lanes 32 (k & 1) + stream
-				const float4 v = *reinterpret_cast<const float4*> (b + (k >> 1) * 1024 + (32 * (k & 1) + cl) * 16);
+				typedef float f4v __attribute__ ((ext_vector_type (4)));
+				f4v v = *reinterpret_cast<const f4v*> (b + (k >> 1) * 1024 + (32 * (k & 1) + cl) * 16);
+				// (the whole 16 bytes, as ONE ds_read_b128: left to itself the compiler reads the channel's two words with a
+				// ds_read2_b32, whose lanes — 16 bytes apart — sit four to a bank)
+				asm volatile ("" : "+v"(v));
 				x[2 * k] = CH ? v.y : v.x; x[2 * k + 1] = CH ? v.w : v.z;
 			}
 		} else {
@@ -314,13 +325,16 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		put_f16 (pos, x);
 		hm4 = hm3; hm3 = hm2; hm2 = hm1; hm1 = m0;
 	};
-	// a pending move: the four slots of the window that starts at ring position w0 are split AGAIN, from the exact samples of the f32
-	// ring, under the new scale (round 4 rescaled the quantised words in place: after a drop of ~100 dB inside one window the older
-	// samples kept 16 bits instead of 22 — ADVICE r4), and the column's un follows for the products
+	// A pending move, found when chunk t + 1 was split (last iteration): the three chunks in front of it — t - 2, t - 1, t, the slots
+	// behind the first of the window that starts at ring position w0 — are split AGAIN, from the exact samples of the f32 ring, under
+	// the new scale (round 4 rescaled the quantised words in place: after a drop of ~100 dB inside one window the older samples kept
+	// 16 bits instead of 22 — ADVICE r4), and the column's un follows.  This iteration's products are not touched by it: their
+	// operands and their un were read an iteration ago, under the old scale, and the window of chunk t held nothing newer; the first
+	// to read the new words are the operands of chunk t + 1, which the products fetch behind the cold barrier.
 	auto rescale = [&] (int w0) {
 		if (pend) {
 #pragma unroll 1
-			for (int k = 0; k < 4; ++k) {
+			for (int k = 1; k < 4; ++k) {
 				int p = w0 + 16 * k; p -= p >= RING ? RING : 0;
 				float x[8];
 				get_f32 (p, x);
@@ -345,17 +359,26 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// every unit's critical path)
 	struct Ops { m16::BFrag B; float4 x0; float un; };
 	Ops ops[2];
-	auto fetch_ops = [&]<bool UB> (Ops& o, int sw) __attribute__ ((always_inline)) {   // sw = the window's first slot = chunk index mod 6
-		// window positions 32 st + 8 kg .. + 7 = piece (2 sw + 4 st + kg) mod 12 of the column
-		int q0 = 2 * sw + kg; q0 -= q0 >= 2 * NSLOT ? 2 * NSLOT : 0;
-		int q1 = q0 + 4; q1 -= q1 >= 2 * NSLOT ? 2 * NSLOT : 0;
-		const int p0 = ucol * HSTRIDE + f16_place (q0, urot), p1 = ucol * HSTRIDE + f16_place (q1, urot);
-		o.B.h0 = *reinterpret_cast<const uint4*> (ringh + p0);
-		o.B.h1 = *reinterpret_cast<const uint4*> (ringh + p1);
-		o.B.l0 = *reinterpret_cast<const uint4*> (ringl + p0);
-		o.B.l1 = *reinterpret_cast<const uint4*> (ringl + p1);
+	// where this lane's operands sit for a window that starts at slot sw = chunk mod 6: window positions 32 st + 8 kg .. + 7 are piece
+	// (2 sw + 4 st + kg) mod 12 of the column — the piece of step 1 at slot sw is the piece of step 0 at slot sw + 2 — and x[n - 24]
+	// of the lane's four frames is at ring position 16 sw + 24 + 4 kg.  Six addresses each, computed once: the loop is unrolled over
+	// the ring's period and names them (round 5's first form computed them per chunk: 25 of a unit's 125 instructions).
+	int pa[NSLOT], ox[NSLOT];
+#pragma unroll
+	for (int k = 0; k < NSLOT; ++k) {
+		int q0 = 2 * k + kg; q0 -= q0 >= 2 * NSLOT ? 2 * NSLOT : 0;
+		pa[k] = ucol * HSTRIDE + f16_place (q0, urot);
+		int o0 = 16 * k + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0;
+		ox[k] = (ucol * RSTRIDE + o0) * 4;
+	}
+	auto fetch_ops = [&]<bool UB, int SW> (Ops& o) __attribute__ ((always_inline)) {
+		constexpr int S1 = (SW + 2) % NSLOT;
+		o.B.h0 = *reinterpret_cast<const uint4*> (ringh + pa[SW]);
+		o.B.h1 = *reinterpret_cast<const uint4*> (ringh + pa[S1]);
+		o.B.l0 = *reinterpret_cast<const uint4*> (ringl + pa[SW]);
+		o.B.l1 = *reinterpret_cast<const uint4*> (ringl + pa[S1]);
 		o.x0 = float4{0.f, 0.f, 0.f, 0.f};
-		if (!UB) { int o0 = 16 * sw + 24 + 4 * kg; o0 -= o0 >= RING ? RING : 0; o.x0 = *reinterpret_cast<const float4*> (ring + ucol * RSTRIDE + o0); }
+		if (!UB) o.x0 = *reinterpret_cast<const float4*> (reinterpret_cast<const unsigned char*> (ring) + ox[SW]);
 		o.un = un_sh[ucol];
 	};
 	// one of the two units of a block (UB = false: phase 1 + the first pair map; true: phases 2, 3 + the second): the MFMAs ...
@@ -380,33 +403,27 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	};
 	// ... and the maps: two attacks in a row are z <- max (z, a z + max (b1, b2), a^2 z + (a b1 + b2)), b = w v — two intercepts per
 	// pair and filter, written straight to where that filter's chain lane reads them as ONE 8-byte word: row [half][frame], then
-	// [group of 16 columns][filter][column] (the unit's sixteen lanes of a frame store 128 contiguous bytes per filter; a chain wave's
-	// 32-lane read groups — sixteen columns x two filters — read 256)
-	auto unit_maps = [&]<bool UB> (int par, const float4& x0, float un, const m16::f4 (&y)[2], int nfl) __attribute__ ((always_inline)) {
+	// [group of 8 columns][filter][column] — eight neighbouring lanes of a unit store 128 contiguous bytes (both filters: one
+	// ds_write2_b64), sixteen neighbouring lanes of a chain wave (eight columns x two filters) read 128, thirty-two 256: no two on a bank
+	auto unit_maps = [&]<bool UB, bool FULL> (int par, const float4& x0, float un, const m16::f4 (&y)[2], int nfl) __attribute__ ((always_inline)) {
 		constexpr int NPH = UB ? 2 : 1;
 		const float xr[4] = { x0.x, x0.y, x0.z, x0.w };
 		const v2f W = v2f{a.w1, a.w2};
-		float pm = 0.f, px = 0.f;
-		unsigned char* const row = cbuf + par * CBUF_B + ((UB ? F : 0) + 4 * kg) * CROW + blk * 256 + cc * 8;
+		unsigned char* const row = cbuf + par * CBUF_B + ((UB ? F : 0) + 4 * kg) * CROW + blk * 256 + (cc >> 3) * 128 + (cc & 7) * 8;
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
-			const float keep = r < nfl ? 1.f : 0.f;
 			unsigned char* const cd = row + r * CROW;
-			v2f g1, g2;
-			if (!UB) {
-				px = __builtin_fmaxf (px, fabsf (xr[r]) * keep);
-				pm = __builtin_fmaxf (pm, fabsf (y[0][r]) * keep);
-				const v2f b1 = W * fabsf (xr[r]), b2 = W * (fabsf (y[0][r]) * un);
-				g1 = max2 (b1, b2); g2 = v2f{__builtin_fmaf (AA.x, b1.x, b2.x), __builtin_fmaf (AA.y, b1.y, b2.y)};
-			} else {
-				pm = __builtin_fmaxf (pm, __builtin_fmaxf (fabsf (y[0][r]), fabsf (y[NPH - 1][r])) * keep);
-				const v2f b3 = W * (fabsf (y[0][r]) * un), b4 = W * (fabsf (y[NPH - 1][r]) * un);
-				g1 = max2 (b3, b4); g2 = v2f{__builtin_fmaf (AA.x, b3.x, b4.x), __builtin_fmaf (AA.y, b3.y, b4.y)};
-			}
+			// the frame's two values of this unit, as the ballistics see them: |x [n - 24]| (exact) and |y1|, or |y2| and |y3| (un-scaled:
+			// un is a power of two)
+			const float va = UB ? fabsf (y[0][r]) * un : fabsf (xr[r]) * 1.0f, vb = fabsf (y[NPH - 1][r]) * un;
+			const v2f ba = W * va, bb = W * vb;
+			const v2f g1 = max2 (ba, bb), g2 = v2f{__builtin_fmaf (AA.x, ba.x, bb.x), __builtin_fmaf (AA.y, ba.y, bb.y)};
 			*reinterpret_cast<v2f*> (cd) = v2f{g1.x, g2.x};                   // filter 1: (c, c')
-			*reinterpret_cast<v2f*> (cd + 128) = v2f{g1.y, g2.y};             // filter 2
+			*reinterpret_cast<v2f*> (cd + 64) = v2f{g1.y, g2.y};              // filter 2
+			// the raw peak (truepeakdsp.cc:65); only the call's ragged last chunk has frames that do not count
+			if (FULL) pk = max3_plain (pk, va, vb);
+			else { const float keep = r < nfl ? 1.f : 0.f; pk = max3_plain (pk, va * keep, vb * keep); }
 		}
-		pk = max3f (pk, px, pm * un);
 	};
 
 	// ---- prologue: the 48 frames before the call (47 of history; frame -48 is never multiplied by a non-zero tap), chunks 0 and 1 ----
@@ -455,7 +472,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// one frame of a chain: z <- max (w3 z, a w3 z + c1, a^2 w3 z + c2), then z <- max (z, a z + c3, a^2 z + c4); m = max (m, z1 + z2)
 	// (the other filter's state sits in the neighbouring lane: one DPP add)
 	auto chain = [&]<bool FULL> (int par, int nf) {
-		const unsigned char* const src = cbuf + par * CBUF_B + (2 * hw_ + (ci >> 4)) * 256 + phi * 128 + (ci & 15) * 8;
+		const unsigned char* const src = cbuf + par * CBUF_B + (4 * hw_ + (ci >> 3)) * 128 + phi * 64 + (ci & 7) * 8;
 		v2f q1[F], q2[F];                                                // the maps do not depend on the state: all sixteen frames' reads go out first
 #pragma unroll
 		for (int f = 0; f < F; ++f) {
@@ -480,37 +497,51 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	int sw = 0;                                                          // chunk t mod 6: the first slot of its window, and its pieces' base
 	const int64_t n_it = n_chunks + 1;
 	// iterations [t0, t1) of the loop (the parity of an iteration is a compile-time constant in `work`: the buffers it selects)
-	auto run_range = [&]<bool SPLITTER> (int64_t t0, int64_t t1, auto&& work) __attribute__ ((always_inline)) {
-		auto iteration = [&]<int PAR> (int64_t t) __attribute__ ((always_inline)) {
-			// A column's scale moved when chunk t + 1 was split (last iteration): the window of chunk t — read by this iteration's
-			// products, and three of its slots by the next one's — is split again and its un follows, in a cold path with its own
-			// barrier.  The flag is uniform; its read goes out HERE and is waited for where the role needs the answer — behind the
-			// chains' frames, behind the products' MFMAs (which run on what was read ahead and are run again if that was stale), with
-			// the split's own data — instead of an LDS round trip at the top of every iteration of every wave.  Every role asks once
-			// and, if the answer is yes, passes the cold barrier once; the split clears the flag behind it.
-			const int flag = flag_sh[PAR];
-			auto moved = [&] () __attribute__ ((always_inline)) { return __builtin_expect (__builtin_amdgcn_readfirstlane (flag) != 0, 0); };
-			PROF_NOW (c0_);
-			work.template operator()<PAR> (t, moved);
-			PROF_NOW (c1_);
-			__syncthreads ();
-			PROF_NOW (c2_);
-			PROF_ADD (0, c1_ - c0_); PROF_ADD (2, c2_ - c1_); PROF_ADD (3, c2_ - c0_);
-			sw = sw + 1 >= NSLOT ? 0 : sw + 1;
-		};
-		// (in pairs: what an even iteration reads ahead for the odd one behind it — the products' operands — stays in the registers it
-		// was loaded into; with one iteration per trip and the parity as a branch the compiler rotated ~40 registers per trip)
-		int64_t t = t0;
-		if (t < t1 && (t & 1)) { iteration.template operator()<1> (t); ++t; }
-		for (; t + 1 < t1; t += 2) {
-			iteration.template operator()<0> (t);
-			iteration.template operator()<1> (t + 1);
-		}
-		if (t < t1) iteration.template operator()<0> (t);
+	// One iteration.  A column's scale moved when chunk t + 1 was split (last iteration): the three chunks in front of it are split
+	// again and its un follows (`rescale`), in a cold path with its own barrier.  The flag is uniform; its read goes out HERE and is
+	// waited for where the role needs the answer — behind the chains' frames, behind the products' MFMAs and in front of the operands
+	// they read ahead, with the split's own data — instead of an LDS round trip at the top of every iteration of every wave.  Every
+	// role asks once and, if the answer is yes, passes the cold barrier once; the split clears the flag behind it.  (PAR = t & 1 and,
+	// for the products, SW = t mod 6 are compile-time constants in `work`: the buffers and ring addresses they select.)
+	auto iteration = [&]<int PAR, int SW> (int64_t t, auto&& work) __attribute__ ((always_inline)) {
+		const int flag = flag_sh[PAR];
+		auto moved = [&] () __attribute__ ((always_inline)) { return __builtin_expect (__builtin_amdgcn_readfirstlane (flag) != 0, 0); };
+		PROF_NOW (c0_);
+		work.template operator()<PAR, SW> (t, moved);
+		PROF_NOW (c1_);
+		__syncthreads ();
+		PROF_NOW (c2_);
+		PROF_ADD (0, c1_ - c0_); PROF_ADD (2, c2_ - c1_); PROF_ADD (3, c2_ - c0_);
+		sw = sw + 1 >= NSLOT ? 0 : sw + 1;
 	};
-	auto run = [&]<bool SPLITTER> (auto&& work) __attribute__ ((always_inline)) { run_range.template operator()<SPLITTER> (0, n_it, work); };
+	// iterations [t0, t1) in pairs: what an even iteration reads ahead for the odd one behind it stays in the registers it was loaded
+	// into (with one iteration per trip and the parity as a branch the compiler rotated ~40 registers per trip)
+	auto run_range = [&] (int64_t t0, int64_t t1, auto&& work) __attribute__ ((always_inline)) {
+		int64_t t = t0;
+		if (t < t1 && (t & 1)) { iteration.template operator()<1, -1> (t, work); ++t; }
+		for (; t + 1 < t1; t += 2) {
+			iteration.template operator()<0, -1> (t, work);
+			iteration.template operator()<1, -1> (t + 1, work);
+		}
+		if (t < t1) iteration.template operator()<0, -1> (t, work);
+	};
+	// ... and all of them in sixes, the ring's period (the products)
+	auto run_six = [&] (auto&& work) __attribute__ ((always_inline)) {
+		int64_t t = 0;
+		for (; t + 5 < n_it; t += 6) {
+			iteration.template operator()<0, 0> (t, work);     iteration.template operator()<1, 1> (t + 1, work);
+			iteration.template operator()<0, 2> (t + 2, work); iteration.template operator()<1, 3> (t + 3, work);
+			iteration.template operator()<0, 4> (t + 4, work); iteration.template operator()<1, 5> (t + 5, work);
+		}
+		if (t < n_it) iteration.template operator()<0, 0> (t++, work);
+		if (t < n_it) iteration.template operator()<1, 1> (t++, work);
+		if (t < n_it) iteration.template operator()<0, 2> (t++, work);
+		if (t < n_it) iteration.template operator()<1, 3> (t++, work);
+		if (t < n_it) iteration.template operator()<0, 4> (t++, work);
+	};
+	auto run = [&] (auto&& work) __attribute__ ((always_inline)) { run_range (0, n_it, work); };
 	if (wid < 2) {
-		run.template operator()<false> ([&]<int PAR> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+		run ([&]<int PAR, int> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
 			if (t >= 1 && !MTR_TPB_DBG_NOCHAIN) {
 				const int64_t left = n_frames - (t - 1) * F;
 				if (left >= F) chain.template operator()<true> (PAR ^ 1, F);
@@ -526,7 +557,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		const int64_t n_whole = n_frames / F;
 		const int64_t t_dma = dma_ok && !MTR_TPB_DBG_NOFETCH ? (n_whole > 2 ? n_whole - 2 : 0) : 0;     // chunks 2 .. n_whole - 1 are staged
 		auto staged = [&]<int CH, bool SENDER> () __attribute__ ((always_inline)) {
-			run_range.template operator()<true> (0, t_dma, [&]<int PAR> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+			run_range (0, t_dma, [&]<int PAR, int> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
 				// chunk t + 5 leaves HBM (into the staging buffer chunk t + 1 was read from, an iteration ago)
 				if (SENDER && (t + 6) * F <= n_frames && !MTR_TPB_DBG_NODMA) dma (t + 5);
 				float x[8];
@@ -548,7 +579,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		};
 		if (wid == 2) staged.template operator()<0, true> ();
 		else          staged.template operator()<C == 2 ? 1 : 0, false> ();
-		run_range.template operator()<true> (t_dma, n_it, [&]<int PAR> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+		run_range (t_dma, n_it, [&]<int PAR, int> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
 			if (moved ()) { rescale (16 * sw); __syncthreads (); if (lane == 0) flag_sh[PAR] = 0; }
 			if (t + 2 < n_chunks && !MTR_TPB_DBG_NOFETCH) {
 				float x[8];
@@ -567,21 +598,22 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 			// might land in with a vmcnt wait inside it)
 #pragma unroll
 			for (int f = 0; f < NF; ++f) asm volatile ("" : "+v"(af[f]));
-			fetch_ops.template operator()<UB> (ops[0], 0);                  // the first chunk's operands
-			run.template operator()<false> ([&]<int PAR> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+			fetch_ops.template operator()<UB, 0> (ops[0]);                  // the first chunk's operands
+			run_six ([&]<int PAR, int SW> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
 				if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
 					m16::f4 y[2];
-					unit_mfma.template operator()<UB> (af, ops[PAR], y);         // on the operands read an iteration ago ...
-					if (moved ()) {                                                // ... which are stale if the window has just been split again
-						__syncthreads ();
-						fetch_ops.template operator()<UB> (ops[PAR], sw);
-						unit_mfma.template operator()<UB> (af, ops[PAR], y);
+					unit_mfma.template operator()<UB> (af, ops[PAR], y);         // on the operands (and the un) read an iteration ago
+					// the next chunk's operands — behind the cold barrier if the rest of its window is being split again under a new scale;
+					// unconditionally (behind the call's last chunk they are whatever the ring holds: nobody uses them, and a branch here
+					// would put a wait for them in front of the maps)
+					__builtin_amdgcn_sched_barrier (0);                            // (the wait for the flag stays BEHIND the MFMAs)
+					if (moved ()) __syncthreads ();
+					fetch_ops.template operator()<UB, (SW + 1) % NSLOT> (ops[PAR ^ 1]);
+					if ((t + 1) * F <= n_frames) unit_maps.template operator()<UB, true> (PAR, ops[PAR].x0, ops[PAR].un, y, 4);
+					else {
+						const int64_t left = n_frames - t * F - 4 * kg;           // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
+						unit_maps.template operator()<UB, false> (PAR, ops[PAR].x0, ops[PAR].un, y, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
 					}
-					// the next chunk's operands, unconditionally (behind the call's last chunk they are whatever the ring holds: nobody uses
-					// them, and a branch here would put a wait for them in front of the maps)
-					fetch_ops.template operator()<UB> (ops[PAR ^ 1], sw + 1 >= NSLOT ? 0 : sw + 1);
-					const int64_t left = n_frames - t * F - 4 * kg;             // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
-					unit_maps.template operator()<UB> (PAR, ops[PAR].x0, ops[PAR].un, y, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
 				} else if (moved ()) __syncthreads ();
 			});
 		};
