@@ -57,7 +57,7 @@ typedef float v2f __attribute__ ((ext_vector_type (2)));
 
 // tools/tpb_prof.hip builds this file with MTR_TPB_PROF: cycles per wave and section for workgroup 0
 #ifdef MTR_TPB_PROF
-__device__ unsigned long long g_tpb_prof[12][4];
+__device__ unsigned long long g_tpb_prof[16][4];
 #define PROF_NOW(v) unsigned long long v; asm volatile ("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
 #define PROF_ADD(i, d) pr[i] += (d)
 #else
@@ -93,8 +93,13 @@ __device__ unsigned long long g_tpb_prof[12][4];
 
 namespace {
 
-constexpr int NW = 12;                         // waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2, 3: fetch + split of the same halves;
-                                               // 4 .. 7: unit A of blocks 0 .. 3; 8 .. 11: unit B — waves w, w + 4, w + 8 share a SIMD
+#ifndef MTR_TPB_NW
+#define MTR_TPB_NW 12
+#endif
+constexpr int NW = MTR_TPB_NW;                 // waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2, 3: fetch + split of the same halves;
+                                               // 4 .. 7: unit A of blocks 0 .. 3; unit B on 10, 11, 14, 15 (8, 9, 12, 13 idle) — waves of equal
+                                               // w mod 4 share a SIMD: a chain wave issues three times what a unit does, so the chains' two SIMDs
+                                               // carry a chain and an A unit each, the other two a split wave, an A unit and two B units
 constexpr int F = 16;                          // frames per chunk = rows of one MFMA block
 constexpr int NCOL = 64;                       // (stream, channel) columns per workgroup: 32 stereo or 64 mono streams
 constexpr int NSLOT = 6;                       // ring slots of 16 samples per column: the 64-sample window of the chunk in the products and
@@ -107,7 +112,7 @@ constexpr int HSTRIDE = 256;                   // bytes per column and array of 
                                                // as four pair words each), piece q at place (q + rot (column)) mod 16 — see f16_rot
 constexpr int HRING_B = NCOL * HSTRIDE;        // one array: hi | lo
 constexpr int AUX_B = 512;                     // float un [NCOL]; int flag [2]
-constexpr int CROW = 1024;                     // a chunk of maps: [half][frame] rows of [group of 8 columns][filter][column] x (c, c') = 8 bytes
+constexpr int CROW = 1024;                     // a chunk of maps: [half][frame] rows of [group of 16 columns][filter][column] x (c, c') = 8 bytes
 constexpr int CBUF_B = 2 * F * CROW;
 constexpr int NSTG = 4;                        // chunks on their way from HBM, as the LDS-DMA leaves them: [chunk % 4][piece 64 i + lane] x 16 bytes
 constexpr int STG_B = NSTG * 4 * 1024;
@@ -130,9 +135,10 @@ __device__ __forceinline__ int f16_place (int q, int rot) { return ((q + rot) & 
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
 __device__ __forceinline__ v2f max2 (v2f a, v2f b) { return v2f{__builtin_fmaxf (a.x, b.x), __builtin_fmaxf (a.y, b.y)}; }
-// max (m, a, b) of values that are already non-negative results of VALU arithmetic: one v_max3_f32 (as a C expression every operand
-// that is not provably quiet costs a canonicalising v_max (x, x) first)
-__device__ __forceinline__ float max3_plain (float m, float a, float b) { float r; asm ("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
+// max (a, b) / max (|a|, b) as ONE instruction (as a C expression every operand that is not provably quiet costs a canonicalising
+// v_max (x, x) first, and an |x| that is used twice a v_and); a NaN loses, as in fmaxf
+__device__ __forceinline__ float max_plain (float a, float b) { float r; asm ("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_abs_plain (float a, float b) { float r; asm ("v_max_f32 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // the maximum of a value over lanes l and l ^ 32, in both (v_permlane32_swap: the upper half of one operand against the lower of the other)
 __device__ __forceinline__ float max_across_halves (float m)
 {
@@ -264,10 +270,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 				x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
 			}
 		}
-		if (!sowner) {
-#pragma unroll
-			for (int i = 0; i < 8; ++i) x[i] = 0.f;
-		}
+		// (a column past the batch holds a copy of stream s0's: nothing of it is ever stored — eight selects per chunk saved)
 	};
 	// ... or straight from memory (any chunk, zeros behind the call's last frame)
 	auto take_ragged = [&] (int64_t j, float (&x)[8]) __attribute__ ((always_inline)) {
@@ -349,10 +352,15 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// A block's products run as TWO units on two waves — unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1);
 	// unit B: phases 2 and 3 (12 MFMAs) and the second.
 	const int cc = lane & 15, kg = lane >> 4;
-	const int blk = (wid - 4) & 3;
+#ifndef MTR_TPB_MAP
+#define MTR_TPB_MAP 1
+#endif
+	const bool unit_a = NW == 16 ? (wid >= 4 && wid < 8) : MTR_TPB_MAP ? (wid >= 4 && !(wid & 2)) : (wid >= 4 && wid < 8);
+	const bool unit_b = NW == 16 ? (wid >= 10 && (wid & 2)) : MTR_TPB_MAP ? (wid >= 4 && (wid & 2)) : wid >= 8;
+	const int blk = NW == 16 ? (unit_a ? wid - 4 : (wid & 1) + (wid >= 12 ? 2 : 0)) : MTR_TPB_MAP ? (wid & 1) + (wid >= 8 ? 2 : 0) : (wid - 4) & 3;
 	const int ucol = 16 * blk + cc;
 	const int urot = f16_rot (ucol);
-	const bool prod_wave = wid >= 4;
+	const bool prod_wave = unit_a || unit_b;
 	float pk = 0.f;                                                      // raw peak of the values this lane produced (column cc of its block)
 	// the operands of a chunk: read from the rings one iteration AHEAD of the products, behind the MFMAs of the chunk before and
 	// under its maps (round 4 read them at the top of the iteration they were used in: ~200 cycles of LDS latency per chunk on
@@ -403,26 +411,38 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	};
 	// ... and the maps: two attacks in a row are z <- max (z, a z + max (b1, b2), a^2 z + (a b1 + b2)), b = w v — two intercepts per
 	// pair and filter, written straight to where that filter's chain lane reads them as ONE 8-byte word: row [half][frame], then
-	// [group of 8 columns][filter][column] — eight neighbouring lanes of a unit store 128 contiguous bytes (both filters: one
-	// ds_write2_b64), sixteen neighbouring lanes of a chain wave (eight columns x two filters) read 128, thirty-two 256: no two on a bank
+	// [group of 16 columns][filter][column] — the sixteen lanes of a unit that share a frame store 128 contiguous bytes per filter (a
+	// ds_write2_b64 is served as two accesses of sixteen-lane groups on 32 banks: measured — with the second filter 64 bytes behind
+	// the first, in groups of eight columns, every one of them cost a second cycle), and a chain wave's thirty-two-lane groups
+	// (sixteen columns x two filters) read 256 contiguous bytes with ds_read_b64, 64 banks — as long as the compiler does not fuse two
+	// of them into a ds_read2st64_b64, which is served in sixteen-lane groups on 32 banks: see `chain`
 	auto unit_maps = [&]<bool UB, bool FULL> (int par, const float4& x0, float un, const m16::f4 (&y)[2], int nfl) __attribute__ ((always_inline)) {
 		constexpr int NPH = UB ? 2 : 1;
 		const float xr[4] = { x0.x, x0.y, x0.z, x0.w };
-		const v2f W = v2f{a.w1, a.w2};
-		unsigned char* const row = cbuf + par * CBUF_B + ((UB ? F : 0) + 4 * kg) * CROW + blk * 256 + (cc >> 3) * 128 + (cc & 7) * 8;
+		const v2f W = v2f{a.w1, a.w2}, WA = v2f{a.w1 * a1, a.w2 * a2};
+		unsigned char* const row = cbuf + par * CBUF_B + ((UB ? F : 0) + 4 * kg) * CROW + blk * 256 + cc * 8;
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			unsigned char* const cd = row + r * CROW;
 			// the frame's two values of this unit, as the ballistics see them: |x [n - 24]| (exact) and |y1|, or |y2| and |y3| (un-scaled:
 			// un is a power of two)
-			const float va = UB ? fabsf (y[0][r]) * un : fabsf (xr[r]) * 1.0f, vb = fabsf (y[NPH - 1][r]) * un;
-			const v2f ba = W * va, bb = W * vb;
-			const v2f g1 = max2 (ba, bb), g2 = v2f{__builtin_fmaf (AA.x, ba.x, bb.x), __builtin_fmaf (AA.y, ba.y, bb.y)};
-			*reinterpret_cast<v2f*> (cd) = v2f{g1.x, g2.x};                   // filter 1: (c, c')
-			*reinterpret_cast<v2f*> (cd + 64) = v2f{g1.y, g2.y};              // filter 2
+			const float va = UB ? fabsf (y[0][r]) * un : xr[r] /* the modifiers below take its magnitude */, vb = fabsf (y[NPH - 1][r]) * un;
+			// c = max (w va, w vb) = w max (va, vb) (w > 0 and rounding is monotone: the same bits), c' = a (w va) + w vb = (w a) va + w vb
+			const float mx = max_abs_plain (va, vb);
+			const v2f bb = W * vb;
+			// (c and c' of a filter as plain VALU instructions whose results the compiler can put side by side for the 8-byte store: a
+			// packed multiply leaves the two filters' c side by side instead, its own v_fmac_f32 overwrites the addend — two moves per
+			// frame and filter either way)
+			float g1x, g1y, g2x, g2y;
+			asm ("v_mul_f32 %0, %1, %2" : "=v"(g1x) : "v"(W.x), "v"(mx));
+			asm ("v_mul_f32 %0, %1, %2" : "=v"(g1y) : "v"(W.y), "v"(mx));
+			asm ("v_fma_f32 %0, %1, |%2|, %3" : "=v"(g2x) : "v"(WA.x), "v"(va), "v"(bb.x));
+			asm ("v_fma_f32 %0, %1, |%2|, %3" : "=v"(g2y) : "v"(WA.y), "v"(va), "v"(bb.y));
+			*reinterpret_cast<v2f*> (cd) = v2f{g1x, g2x};                     // filter 1: (c, c')
+			*reinterpret_cast<v2f*> (cd + 128) = v2f{g1y, g2y};               // filter 2
 			// the raw peak (truepeakdsp.cc:65); only the call's ragged last chunk has frames that do not count
-			if (FULL) pk = max3_plain (pk, va, vb);
-			else { const float keep = r < nfl ? 1.f : 0.f; pk = max3_plain (pk, va * keep, vb * keep); }
+			if (FULL) pk = max_plain (pk, mx);
+			else pk = max_plain (pk, mx * (r < nfl ? 1.f : 0.f));
 		}
 	};
 
@@ -471,16 +491,32 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 #endif
 	// one frame of a chain: z <- max (w3 z, a w3 z + c1, a^2 w3 z + c2), then z <- max (z, a z + c3, a^2 z + c4); m = max (m, z1 + z2)
 	// (the other filter's state sits in the neighbouring lane: one DPP add)
-	auto chain = [&]<bool FULL> (int par, int nf) {
-		const unsigned char* const src = cbuf + par * CBUF_B + (4 * hw_ + (ci >> 3)) * 128 + phi * 64 + (ci & 7) * 8;
-		v2f q1[F], q2[F];                                                // the maps do not depend on the state: all sixteen frames' reads go out first
+	// The sixteen frames' maps are read with ds_read_b64 written out as inline assembly, in two batches of eight frames, each waited
+	// for by hand: left to the compiler the 32 reads become 16 ds_read2st64_b64 — half the instructions, but served at half the
+	// width and, in this layout, two lanes to a bank: 512 LDS cycles per chunk and workgroup where these take 128 (the LDS was busy
+	// 74 % of the time with them: the kernel's bound after the instruction diet).  The waits name the registers they protect —
+	// the compiler knows nothing of what an asm statement has in flight — and the second one the state as well, so that it stays
+	// behind the first eight frames.
+	const uint32_t csrc = (uint32_t) (size_t) (__attribute__ ((address_space (3))) unsigned char*) cbuf
+	                      + (uint32_t) ((2 * hw_ + (ci >> 4)) * 256 + phi * 128 + (ci & 15) * 8);
+#define TPB_RD(dst, off) asm volatile ("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(csrc), "n"(off))
+#define TPB_WAIT8(q, b) asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(q##1[b]), "+v"(q##1[b + 1]), "+v"(q##1[b + 2]), "+v"(q##1[b + 3]), "+v"(q##1[b + 4]), "+v"(q##1[b + 5]), "+v"(q##1[b + 6]), "+v"(q##1[b + 7]), \
+	                                              "+v"(q##2[b]), "+v"(q##2[b + 1]), "+v"(q##2[b + 2]), "+v"(q##2[b + 3]), "+v"(q##2[b + 4]), "+v"(q##2[b + 5]), "+v"(q##2[b + 6]), "+v"(q##2[b + 7]), "+v"(z))
+	auto chain = [&]<bool FULL, int PARITY> (int nf) {
+		constexpr int P = PARITY * CBUF_B;
+		v2f q1[F], q2[F];
+		TPB_RD (q1[0], P + 0 * CROW); TPB_RD (q2[0], P + (F + 0) * CROW); TPB_RD (q1[1], P + 1 * CROW); TPB_RD (q2[1], P + (F + 1) * CROW);
+		TPB_RD (q1[2], P + 2 * CROW); TPB_RD (q2[2], P + (F + 2) * CROW); TPB_RD (q1[3], P + 3 * CROW); TPB_RD (q2[3], P + (F + 3) * CROW);
+		TPB_RD (q1[4], P + 4 * CROW); TPB_RD (q2[4], P + (F + 4) * CROW); TPB_RD (q1[5], P + 5 * CROW); TPB_RD (q2[5], P + (F + 5) * CROW);
+		TPB_RD (q1[6], P + 6 * CROW); TPB_RD (q2[6], P + (F + 6) * CROW); TPB_RD (q1[7], P + 7 * CROW); TPB_RD (q2[7], P + (F + 7) * CROW);
+		TPB_WAIT8 (q, 0);
+		TPB_RD (q1[8], P + 8 * CROW); TPB_RD (q2[8], P + (F + 8) * CROW); TPB_RD (q1[9], P + 9 * CROW); TPB_RD (q2[9], P + (F + 9) * CROW);
+		TPB_RD (q1[10], P + 10 * CROW); TPB_RD (q2[10], P + (F + 10) * CROW); TPB_RD (q1[11], P + 11 * CROW); TPB_RD (q2[11], P + (F + 11) * CROW);
+		TPB_RD (q1[12], P + 12 * CROW); TPB_RD (q2[12], P + (F + 12) * CROW); TPB_RD (q1[13], P + 13 * CROW); TPB_RD (q2[13], P + (F + 13) * CROW);
+		TPB_RD (q1[14], P + 14 * CROW); TPB_RD (q2[14], P + (F + 14) * CROW); TPB_RD (q1[15], P + 15 * CROW); TPB_RD (q2[15], P + (F + 15) * CROW);
 #pragma unroll
 		for (int f = 0; f < F; ++f) {
-			q1[f] = *reinterpret_cast<const v2f*> (src + f * CROW);
-			q2[f] = *reinterpret_cast<const v2f*> (src + (F + f) * CROW);
-		}
-#pragma unroll
-		for (int f = 0; f < F; ++f) {
+			if (f == 8) TPB_WAIT8 (q, 8);
 			if (FULL || f < nf) {                                            // wave-uniform: only the call's last chunk is short
 				const float u0 = sl0 * z, u1 = __builtin_fmaf (sl1, z, q1[f].x), u2 = __builtin_fmaf (sl2_, z, q1[f].y);
 				const float zh = max3f (u0, u1, u2);
@@ -491,6 +527,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 			}
 		}
 	};
+#undef TPB_RD
+#undef TPB_WAIT8
 	// THE LOOP, once per role: every wave runs the same iterations and the same barriers, but each role's copy of the loop has
 	// its own registers (in ONE loop with the roles as branches the compiler re-fetched the products' twelve tap fragments from
 	// global memory in every iteration).
@@ -544,8 +582,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		run ([&]<int PAR, int> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
 			if (t >= 1 && !MTR_TPB_DBG_NOCHAIN) {
 				const int64_t left = n_frames - (t - 1) * F;
-				if (left >= F) chain.template operator()<true> (PAR ^ 1, F);
-				else chain.template operator()<false> (PAR ^ 1, (int) left);
+				if (left >= F) chain.template operator()<true, PAR ^ 1> (F);
+				else chain.template operator()<false, PAR ^ 1> ((int) left);
 			}
 			if (moved ()) __syncthreads ();
 		});
@@ -617,8 +655,9 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 				} else if (moved ()) __syncthreads ();
 			});
 		};
-		if (wid < 8) run_unit.template operator()<false> ();
-		else         run_unit.template operator()<true> ();
+		if (unit_a)      run_unit.template operator()<false> ();
+		else if (unit_b) run_unit.template operator()<true> ();
+		else run ([&]<int, int> (int64_t, auto&& moved) __attribute__ ((always_inline)) { if (moved ()) __syncthreads (); });   // (idle: keeps the barriers' count)
 	}
 #ifdef MTR_TPB_PROF
 	if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 4; ++i) g_tpb_prof[wid][i] = pr[i];

@@ -41,12 +41,12 @@ int main (int argc, char** argv)
 	hipEventRecord (e1);
 	hipDeviceSynchronize ();
 	float ms; hipEventElapsedTime (&ms, e0, e1);
-	unsigned long long pr[12][4];
+	unsigned long long pr[16][4] = {};
 	hipMemcpyFromSymbol (pr, HIP_SYMBOL (g_tpb_prof), sizeof pr);
 	const double nchunk = (double) ((T + F - 1) / F + 1);
 	printf ("stride %llu frames (= 128 B x %.3f): ", (unsigned long long) ST, ST * 8 / 128.0);
 	printf ("S=%u T=%llu: %.3f ms, %.0f ns per chunk of %d frames\n", S, (unsigned long long) T, ms, ms * 1e6 / nchunk, F);
-	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2: LDS-DMA + split of columns 0 .. 31; 3: split of 32 .. 63; 4 .. 7: unit A of blocks 0 .. 3 (phase 1 + first pair map); 8 .. 11: unit B (phases 2, 3 + second pair map); waves w, w + 4, w + 8 share a SIMD)\n");
-	for (int w = 0; w < NW; ++w) printf ("  %2d  %7.1f  %7.1f  %7.1f\n", w, pr[w][0] / nchunk, pr[w][2] / nchunk, pr[w][3] / nchunk);
+	printf ("shader cycles per chunk:\n wave  work  barrier wait  total   (waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2: LDS-DMA + split of columns 0 .. 31; 3: split of 32 .. 63; 4 .. 7: unit A of blocks 0 .. 3 (phase 1 + first pair map); 10, 11, 14, 15: unit B (phases 2, 3 + second pair map; 8 .. 11 with MTR_TPB_NW=12); the rest idle; waves of equal w mod 4 share a SIMD)\n");
+	for (int w = 0; w < NW && w < 16; ++w) printf ("  %2d  %7.1f  %7.1f  %7.1f\n", w, pr[w][0] / nchunk, pr[w][2] / nchunk, pr[w][3] / nchunk);
 	return 0;
 }
