@@ -8,46 +8,39 @@
 //     entry and offset by 1e-20f on exit.
 //
 // The attack / release recurrence is a monotone piece-wise linear map of the state; compositions grow a piece per
-// value, so it is not a cheap associative scan and time stays serial per (stream, channel).  What this kernel does
-// (round 4's form; round 3's split every 64-sample window again for every 16-frame chunk — each sample four times, in
-// the lanes of the products — which made a block of products a 1600-cycle dependent sequence):
+// value, so it is not a cheap associative scan and time stays serial per (stream, channel, filter).  What this kernel does
+// (round 5's form; round 4's — one wave walking all 64 chains as packed pairs, one wave fetching and splitting, operands
+// read in the iteration that used them — is in git and in profiles/r04_tpb.md):
 //
 //   * `if (v > z) z += w (v - z)` is z <- max (z, a z + w v) with a = 1 - w: a monotone max-affine map, and maps of
-//     that kind compose.  The intercepts depend on the values only — any lane can form them, for any frame — so what is
-//     left ON the chain per frame and filter is the release, two fused multiply-adds and a v_max3, twice (the frame's
-//     four values as two pair maps, see below; round 3 applied them as one five-piece map).  Exact
-//     in real arithmetic; in f32 a few ulps from the reference's sequence (held to the 2e-6 of
-//     tests/test_gpu_parity.py::test_truepeak_ballistics_*; 600 fuzzed shapes: <= 7.4e-7 up to 48 kHz, 1.6e-6 at 192 kHz).
+//     that kind compose.  Two attacks in a row are z <- max (z, a z + c, a^2 z + c'), c = w max (v1, v2), c' = (w a) v1 + w v2:
+//     the intercepts depend on the values only — any lane can form them, for any frame — so what is left ON the chain per
+//     frame and filter is the release (folded into the first pair's slopes), four fused multiply-adds, a multiply and two
+//     v_max3, plus a DPP add and half a v_max3 for m = max (z1 + z2).  Exact in real arithmetic; in f32 a few ulps from the
+//     reference's sequence (tests/test_gpu_parity.py::test_truepeak_ballistics_*: 4e-6 of the value; tools/fuzz_tpb.py).
 //   * the interpolator is the matrix-pipe one of mtr_mfma16_fir.h (samples and taps as two f16 halves, three partial
 //     products, f32 accumulation: within 4e-7 of the exact-f32 chain): a workgroup owns 64 (stream, channel)
 //     columns = 4 blocks of 16, a chunk is 16 frames = the rows of one block.
-//   * EVERY SAMPLE IS SPLIT ONCE, by the wave that fetched it (lane = column), into a ring of f16 hi / lo pair words
-//     (five slots of 16 samples per column, 176 bytes per column and array: conflict-free 16-byte accesses), under a
-//     power-of-two scale per column that follows the window's maximum with hysteresis: it stands while the maximum of
-//     the 64-sample window stays in [2^7, 2^15) scaled, and when it has to move — a sample too large for it, or a window
-//     that has become 2^5 quieter than the scale was made for — the column's three older slots are rescaled in place (a
-//     power of two: exact but for what falls below f16's range, 2^-27 of the new maximum) in a cold path with its own
-//     barrier.  22 bits of every sample within 2^-11 of the window's maximum, as with a scale per window.  The products
-//     then READ their operands (four ds_read_b128 per block) instead of forming them; phase 0 (x[n - 24]) comes from an
-//     f32 ring the same wave fills, exactly.
-//   * a chunk travels HBM -> LDS by LDS-DMA, three iterations ahead of its products, issued as inline assembly: the
-//     compiler's own vmcnt bookkeeping (conservative at loop back edges and where paths join, and aware that an LDS-DMA
-//     writes LDS) waited for whatever was in flight at every barrier — in rounds 2 and 3, and in this round's first four
-//     forms, the wave that fetched sat out HBM's latency in every chunk, and the whole workgroup with it at the barrier.
-//   * the lanes that produce a frame's four values form its maps as well: two attacks in a row are
-//     z <- max (z, a z + max (b1, b2), a^2 z + (a b1 + b2)), b = w v, so a frame is two such maps applied one after the
-//     other on the chain — two intercepts per pair and filter, ten instructions per frame and column instead of
-//     twenty-two for the frame's single five-piece map — written straight to where the chains read them: no values in
-//     LDS, no map waves, one chunk less between products and chains.
-//   * twelve waves, three per SIMD (156 registers), each with ITS OWN copy of the loop (one loop with the roles as branches
-//     made the compiler fetch the products' tap fragments from global memory in every iteration): wave 0 walks the 64 chains
-//     (chunk t - 1); a block's products run as TWO units on two waves — unit A: phase 1 (6 MFMAs) and the frame's first
-//     pair map (x[n - 24], y1), unit B: phases 2 and 3 (12 MFMAs) and the second — the B units on waves 1, 5, 2, 6, the A
-//     units on waves 4, 9, 10, 7 (two B and an A on SIMDs 1 and 2, an A beside the chains, an A beside the split); wave 3
-//     sends chunk t + 3 on its way and splits chunk t + 1; waves 8 and 11 only keep the barriers' count.  One barrier per
-//     chunk; the chains (~1400 cycles per chunk) are what bounds it now.
-//     (The forms this one was measured against — one or two blocks per products wave, values and five-piece maps through
-//     LDS, map waves — live in git and in profiles/r04_tpb.md, r04_tpb_experiments.md; ONE form ships.)
+//   * EVERY SAMPLE IS SPLIT ONCE into a ring of f16 hi / lo pair words (six slots of 16 samples per column), under a
+//     power-of-two scale per column that follows the maximum of five slots with hysteresis: it stands while that maximum
+//     stays in [2^7, 2^15) scaled, and when it has to move — a sample too large for it, or a stretch that has become 2^5
+//     quieter than the scale was made for — the new chunk is written under the new scale and the three chunks in front of it
+//     are split AGAIN from the exact f32 ring, in a cold path with its own barrier (`rescale`).  The products READ their
+//     operands (four ds_read_b128 per unit, from places chosen so that no two lanes of a read group share a bank: f16_rot);
+//     phase 0 (x[n - 24]) comes from the f32 ring, exactly.
+//   * a chunk travels HBM -> LDS by LDS-DMA issued as inline assembly (the compiler's own vmcnt bookkeeping would wait for
+//     whatever is in flight at every barrier), five chunks ahead of its split, which is two chunks ahead of its products.
+//   * TWELVE WAVES, three per SIMD, each with its own copy of the loop, one barrier per chunk:
+//       waves 0, 1   the chains of columns 0 .. 31 | 32 .. 63: lane = (column, filter), plain f32 (round 4: one wave, both
+//                    filters of 64 columns as packed pairs — eleven instructions per frame on ONE wave; here 8.5 on each of two);
+//       waves 2, 3   the split of the same halves: lane = (half of a chunk, column); wave 2 also sends the LDS-DMA;
+//       the rest     a block's products as TWO units — unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1);
+//                    unit B: phases 2 and 3 (12 MFMAs) and the second — whose operands are read one iteration AHEAD, behind
+//                    the MFMAs of the chunk before and under its maps.
+//     What bounds it is what a SIMD can issue per chunk (VALU + matrix pipe busy 84 % of the time): round 5 cut the
+//     workgroup's VALU instructions per chunk from 963 to ~850 while adding a second chain wave, removed the LDS bank
+//     conflicts (SQ_LDS_BANK_CONFLICT 1.1e9 -> 1.2e8 per launch) and the LDS latency on every role's critical path.
+//     22.9 -> 18.7 ms per 8192 streams x 10 s (profiles/r05_tpb.md).
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -93,13 +86,13 @@ __device__ unsigned long long g_tpb_prof[16][4];
 
 namespace {
 
-#ifndef MTR_TPB_NW
-#define MTR_TPB_NW 12
-#endif
-constexpr int NW = MTR_TPB_NW;                 // waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2, 3: fetch + split of the same halves;
-                                               // 4 .. 7: unit A of blocks 0 .. 3; unit B on 10, 11, 14, 15 (8, 9, 12, 13 idle) — waves of equal
-                                               // w mod 4 share a SIMD: a chain wave issues three times what a unit does, so the chains' two SIMDs
-                                               // carry a chain and an A unit each, the other two a split wave, an A unit and two B units
+constexpr int NW = 12;                         // waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2, 3: fetch + split of the same halves;
+                                               // unit A of blocks 0 .. 3 on waves 4, 5, 8, 9, unit B on 6, 7, 10, 11.  Waves of equal w mod 4
+                                               // share a SIMD, and what a SIMD issues per chunk is what bounds the kernel: the chains' two SIMDs
+                                               // carry a chain (~150 VALU instructions) and two A units (6 MFMAs each), the other two a split
+                                               // wave (~60) and two B units (12 MFMAs each).  (A on 4 .. 7 and B on 8 .. 11 — a chain, an A and
+                                               // a B per SIMD — is 1.5 % slower; sixteen waves with the B units moved off the chains' SIMDs
+                                               // balance better and lose it at the barrier: profiles/r05_tpb.md)
 constexpr int F = 16;                          // frames per chunk = rows of one MFMA block
 constexpr int NCOL = 64;                       // (stream, channel) columns per workgroup: 32 stereo or 64 mono streams
 constexpr int NSLOT = 6;                       // ring slots of 16 samples per column: the 64-sample window of the chunk in the products and
@@ -114,7 +107,10 @@ constexpr int HRING_B = NCOL * HSTRIDE;        // one array: hi | lo
 constexpr int AUX_B = 512;                     // float un [NCOL]; int flag [2]
 constexpr int CROW = 1024;                     // a chunk of maps: [half][frame] rows of [group of 16 columns][filter][column] x (c, c') = 8 bytes
 constexpr int CBUF_B = 2 * F * CROW;
-constexpr int NSTG = 4;                        // chunks on their way from HBM, as the LDS-DMA leaves them: [chunk % 4][piece 64 i + lane] x 16 bytes
+constexpr int NSTG = 4;                        // staging buffers, as the LDS-DMA leaves a chunk: [chunk % 4][piece 64 i + lane] x 16 bytes — the chunk the
+                                               // split reads and the three behind it that are landing or on their way from HBM
+constexpr int AHEAD = 5;                       // iteration t sends chunk t + AHEAD and waits for chunk t + 3: two chunks' time of flight behind
+                                               // the one that is landing (AHEAD = 7 with eight buffers, four chunks: measured 1 % SLOWER)
 constexpr int STG_B = NSTG * 4 * 1024;
 constexpr int LDS_BYTES = RING_B + 2 * HRING_B + AUX_B + 2 * CBUF_B + STG_B;
 constexpr int NTHREADS = 64 * NW;
@@ -134,7 +130,6 @@ __device__ __forceinline__ int f16_rot (int col) { return (col & 6) | ((col & 1)
 __device__ __forceinline__ int f16_place (int q, int rot) { return ((q + rot) & 15) << 4; }
 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
-__device__ __forceinline__ v2f max2 (v2f a, v2f b) { return v2f{__builtin_fmaxf (a.x, b.x), __builtin_fmaxf (a.y, b.y)}; }
 // max (a, b) / max (|a|, b) as ONE instruction (as a C expression every operand that is not provably quiet costs a canonicalising
 // v_max (x, x) first, and an |x| that is used twice a v_and); a NaN loses, as in fmaxf
 __device__ __forceinline__ float max_plain (float a, float b) { float r; asm ("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -201,7 +196,6 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	const float ap = phi ? a2 : a1;
 	const float sl0 = a.w3, sl1 = (float) ((double) a.w3 * (double) ap), sl2_ = (float) ((double) a.w3 * (double) ap * (double) ap);
 	const float ap2 = (float) ((double) ap * (double) ap);
-	const v2f AA = v2f{a1, a2};
 
 	// ---- the split (waves 2, 3): lane = (half hh of the lanes, column cl of the wave's 32); it owns samples 8 hp .. 8 hp + 7 of every chunk ----
 	const int hh = lane >> 5, cl = lane & 31;
@@ -249,6 +243,14 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		              "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
 		              "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
 		              : "=&s"(m0_was) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(l) : "memory", "scc");
+	};
+	// a chunk has landed when at most the DMA instructions (four per chunk) of the `younger` chunks behind it are outstanding
+	auto dma_wait = [] (int younger) __attribute__ ((always_inline)) {
+		if (younger >= 4)      asm volatile ("s_waitcnt vmcnt(16)" ::: "memory");
+		else if (younger == 3) asm volatile ("s_waitcnt vmcnt(12)" ::: "memory");
+		else if (younger == 2) asm volatile ("s_waitcnt vmcnt(8)" ::: "memory");
+		else if (younger == 1) asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
+		else                   asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 	};
 	// this lane's eight samples of chunk j: from the staging buffer the LDS-DMA filled ...
 	auto take_staged = [&]<int CH> (int64_t j, float (&x)[8]) __attribute__ ((always_inline)) {
@@ -352,12 +354,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// A block's products run as TWO units on two waves — unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1);
 	// unit B: phases 2 and 3 (12 MFMAs) and the second.
 	const int cc = lane & 15, kg = lane >> 4;
-#ifndef MTR_TPB_MAP
-#define MTR_TPB_MAP 1
-#endif
-	const bool unit_a = NW == 16 ? (wid >= 4 && wid < 8) : MTR_TPB_MAP ? (wid >= 4 && !(wid & 2)) : (wid >= 4 && wid < 8);
-	const bool unit_b = NW == 16 ? (wid >= 10 && (wid & 2)) : MTR_TPB_MAP ? (wid >= 4 && (wid & 2)) : wid >= 8;
-	const int blk = NW == 16 ? (unit_a ? wid - 4 : (wid & 1) + (wid >= 12 ? 2 : 0)) : MTR_TPB_MAP ? (wid & 1) + (wid >= 8 ? 2 : 0) : (wid - 4) & 3;
+	const bool unit_a = wid >= 4 && !(wid & 2), unit_b = wid >= 4 && (wid & 2);
+	const int blk = (wid & 1) + (wid >= 8 ? 2 : 0);
 	const int ucol = 16 * blk + cc;
 	const int urot = f16_rot (ucol);
 	const bool prod_wave = unit_a || unit_b;
@@ -472,14 +470,12 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		put_f32 (64, xc1); put_f16 (64, xc1);
 		un_sh[scol] = cs.un;
 		hm4 = hm3; hm3 = hm2; hm2 = hm1; hm1 = m0;
-		if (wid == 2 && dma_ok && !MTR_TPB_DBG_NOFETCH && !MTR_TPB_DBG_NODMA) {   // chunks 2, 3 and 4: on their way before the loop starts,
+		if (wid == 2 && dma_ok && !MTR_TPB_DBG_NOFETCH && !MTR_TPB_DBG_NODMA) {   // chunks 2 .. 4: on their way before the loop starts,
 			int sent = 0;                                                  // and chunk 2 has landed behind the barrier below
-			if (3 * F <= n_frames) { dma (2); ++sent; }
-			if (4 * F <= n_frames) { dma (3); ++sent; }
-			if (5 * F <= n_frames) { dma (4); ++sent; }
-			if (sent == 3)      asm volatile ("s_waitcnt vmcnt(8)" ::: "memory");
-			else if (sent == 2) asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
-			else                asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+			for (int j = 2; j < AHEAD; ++j)
+				if ((j + 1) * F <= n_frames) { dma (j); ++sent; }
+			dma_wait (sent - 1);
 		}
 	}
 	__syncthreads ();
@@ -597,7 +593,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		auto staged = [&]<int CH, bool SENDER> () __attribute__ ((always_inline)) {
 			run_range (0, t_dma, [&]<int PAR, int> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
 				// chunk t + 5 leaves HBM (into the staging buffer chunk t + 1 was read from, an iteration ago)
-				if (SENDER && (t + 6) * F <= n_frames && !MTR_TPB_DBG_NODMA) dma (t + 5);
+				if (SENDER && (t + AHEAD + 1) * F <= n_frames && !MTR_TPB_DBG_NODMA) dma (t + AHEAD);
 				float x[8];
 				take_staged.template operator()<CH> (t + 2, x);
 				if (moved ()) { rescale (16 * sw); __syncthreads (); if (lane == 0) flag_sh[PAR] = 0; }
@@ -608,10 +604,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 				// chunk t + 3 — the next iteration's — has landed when at most the DMA instructions of the younger chunks are outstanding;
 				// the wait stands in front of the barrier that lets BOTH split waves read it
 				if (SENDER && !MTR_TPB_DBG_NODMA) {
-					const int younger = ((t + 5) * F <= n_frames ? 1 : 0) + ((t + 6) * F <= n_frames ? 1 : 0);
-					if (younger == 2)      asm volatile ("s_waitcnt vmcnt(8)" ::: "memory");
-					else if (younger == 1) asm volatile ("s_waitcnt vmcnt(4)" ::: "memory");
-					else                   asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+					int younger = 0;
+#pragma unroll
+					for (int k = 4; k <= AHEAD; ++k) younger += (t + k + 1) * F <= n_frames ? 1 : 0;
+					dma_wait (younger);
 				}
 			});
 		};
