@@ -124,9 +124,9 @@ def kernel_sha():
 def committed_traffic(meters, S, T, layout):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md):
     the counters cannot be read from inside this process, so the figure is reported only for the very workload AND the
-    very kernel sources it was measured on (profiles/r04_traffic.json carries their hash); otherwise null."""
+    very kernel sources it was measured on (profiles/r05_traffic.json carries their hash); otherwise null."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic.json")))
         w = tj["workload"]
         if (meters, S, T, layout) == (w["meters"], w["streams_per_gpu"], w["frames_per_stream"], w["layout"]) \
                 and tj["kernel_sha16"] == kernel_sha():
@@ -611,9 +611,9 @@ def run(args, rank, local, world):
             _, _, bk, w, _ = timed(S, T, M.METER_TPBALLIST, steps=2)
             cfgs["true-peak ballistics (TruePeakdsp::process), 8192 streams x 10 s"] = {
                 "kernel": "k_tpb", "kernel_ms": bk, "wall_ms": w, "frac": frac(S, T, bk),
-                "bound": "the serial chains: one wave walks a workgroup's 64 (stream, channel) chains, ~1400 cycles per 16-frame chunk (two pair maps per "
-                         "frame on the critical path); the products (two units per block on two waves), the split and the LDS-DMA fetch run "
-                         "beside it (DESIGN.md 3.5)"}
+                "bound": "what a SIMD can issue per 16-frame chunk: the chains (two waves: lane = (column, filter), 8.5 instructions per frame), the "
+                         "products (two units per block on two waves, operands read an iteration ahead) with their maps, the split (two waves) — "
+                         "VALU + matrix pipe busy 84 % of the time, three waves per SIMD, one barrier per chunk (DESIGN.md 3.5)"}
             extra["configs"] = cfgs
             # SURVEY.md 8d "Timing": the end-to-end figure of a host whose audio is NOT resident — pageable host memory through
             # mtr_engine_process_host (chunks of streams: chunk k + 1 crosses the link under the kernels of chunk k) — next to a

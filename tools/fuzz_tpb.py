@@ -12,6 +12,9 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 orc = Oracle()
 TOL = 4e-6          # level and peak, RELATIVE TO THE VALUE (the levels drawn below go down to 2^-13: a bound on max (1, value) would say nothing)
+FLOOR = 4e-7        # ... plus this much of the largest INPUT magnitude inside the interpolator's window of the call: an output that is the
+                    # cancelling tail of a 48-tap sum (the first frames behind silence, e.g.) is far smaller than its terms, and any two correct
+                    # f32 evaluations of it — the reference's fmaf chain is one — differ by ~2^-24 x sum |g| |x| = 1.5e-7 of that magnitude
 bad = 0
 worst = {}
 for seed in range(first, first + count):
@@ -55,9 +58,12 @@ for seed in range(first, first + count):
                         seg = np.ascontiguousarray(ch[o:min(o + 8192, pos + n)])
                         orc.lib.mo_tp_process(C.byref(t), seg, seg.size); orc.lib.mo_tp_read2(C.byref(t), C.byref(m), C.byref(p))
                         mm, pp = max(mm, m.value), max(pp, p.value)
-                    worst[fs] = max(worst.get(fs, 0.0), abs(got[i][s][c][0] - mm) / max(1e-37, mm), abs(got[i][s][c][1] - pp) / max(1e-37, pp))
-                    assert abs(got[i][s][c][0] - mm) <= TOL * mm + 1e-37, ("m", s, c, i, got[i][s][c][0], mm)
-                    assert abs(got[i][s][c][1] - pp) <= TOL * pp + 1e-37, ("p", s, c, i, got[i][s][c][1], pp)
+                    wmax = float(np.abs(ch[max(pos - 47, 0):pos + n]).max())
+                    for k, want in ((0, mm), (1, pp)):
+                        dev = abs(got[i][s][c][k] - want)
+                        if dev > FLOOR * wmax:
+                            worst[fs] = max(worst.get(fs, 0.0), dev / max(1e-37, want))
+                        assert dev <= TOL * want + FLOOR * wmax + 1e-37, ("mp"[k], s, c, i, got[i][s][c][k], want, wmax)
                     pos += n
     except AssertionError as ex:
         bad += 1
