@@ -329,11 +329,10 @@ def run(args, rank, local, world):
     def make():
         if shared and os.environ.get("MTR_BENCH_TRY_RCCL") != "1":
             raise RuntimeError("not tried (MTR_BENCH_SHARED_GPU)")
-        if fault.startswith("sleep_in_init:"):
-            _, r, sec = fault.split(":")
-            if int(r) == rank:
-                time.sleep(float(sec))
-        return mdist.make_comm(rank, world, local, timeout_ms=int(1e3 * comm_timeout_s) if world > 1 else 0)
+        def late():                                               # (this rank holds the id and keeps the others waiting inside RCCL)
+            if fault.startswith("sleep_in_init:") and int(fault.split(":")[1]) == rank:
+                time.sleep(float(fault.split(":")[2]))
+        return mdist.make_comm(rank, world, local, timeout_ms=int(1e3 * comm_timeout_s) if world > 1 else 0, before_init=late)
 
     t_neg = time.perf_counter()
     comm, group, collective = mdist.agree_on_collective(

@@ -30,13 +30,16 @@ def all_reduce_aggregate(hist, maxv, group=None):
     return hist, maxv
 
 
-def make_comm(rank, world, device=0, timeout_ms=0):
+def make_comm(rank, world, device=0, timeout_ms=0, before_init=None):
     """One engine communicator per rank: rank 0 draws the RCCL id, torch.distributed (any backend) ships it.
-    timeout_ms > 0: mtr_comm_init_timeout — a rank that never arrives costs the others that long, not forever."""
+    timeout_ms > 0: mtr_comm_init_timeout — a rank that never arrives costs the others that long, not forever.
+    before_init (tests): called between the id's arrival and mtr_comm_init — where a rank can be made late for the others."""
     import torch.distributed as dist
     uid = [_engine.comm_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
+    if before_init:
+        before_init()
     return _engine.Comm(rank, world, uid[0], device, timeout_ms=timeout_ms)
 
 

@@ -75,11 +75,12 @@ def test_two_ranks_share_the_gpu_and_reduce_like_one_engine(segments):
 
 
 def test_a_rank_that_sleeps_through_the_communicator_cannot_hang_the_job():
-    """VERDICT r4 item 2: the job's first contact with RCCL is bounded.  Rank 1 sleeps 25 s before it joins mtr_comm_init;
-    rank 0's mtr_comm_init_timeout (ncclCommInitRankConfig non-blocking, ncclCommGetAsyncError polled) gives up after
-    MTR_BENCH_COMM_TIMEOUT_S = 6 s and aborts its communicator; rank 1, arriving late, fails or times out as well; the ranks
-    vote over gloo, fall back together, and rank 0 prints exactly ONE line that names the fallback — in tens of seconds,
-    not after the 30 minutes a blocking ncclCommInitRank plus gloo's default timeout would take."""
+    """the job's first contact with RCCL is bounded.  Rank 1 holds the communicator's id and sleeps 25 s
+    before it joins mtr_comm_init; rank 0 is INSIDE RCCL meanwhile (the bootstrap waits for every rank), and its
+    mtr_comm_init_timeout (ncclCommInitRankConfig non-blocking, ncclCommGetAsyncError polled) gives up after
+    MTR_BENCH_COMM_TIMEOUT_S = 6 s and aborts the communicator; rank 1, arriving late, fails or times out as well; the ranks
+    vote over gloo, fall back together, and rank 0 prints exactly ONE line that names the fallback and the deadline that
+    passed — in tens of seconds, not after the 30 minutes a blocking ncclCommInitRank plus gloo's default timeout would take."""
     import time
     env = dict(os.environ, MTR_BENCH_SHARED_GPU="1", MTR_BENCH_TRY_RCCL="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
                MTR_BENCH_COMM_TIMEOUT_S="6", MTR_BENCH_FAULT="sleep_in_init:1:25", MTR_BENCH_CTRL_TIMEOUT_S="120")
@@ -96,6 +97,7 @@ def test_a_rank_that_sleeps_through_the_communicator_cannot_hang_the_job():
     line = json.loads(lines[0])
     coll = line["config"]["collective"]
     assert line["n_gpus"] == 2 and "gloo" in coll and "mtr_comm_init failed on a rank" in coll, coll
+    assert "no answer from RCCL within 6000 ms" in coll, coll          # rank 0 (whose reason the line carries) ran into its deadline
     assert line["config"]["comm_init_ms"] is None and line["config"]["rccl_version"] >= 21800
     assert 20e3 < line["config"]["comm_negotiation_ms"] < 120e3, line["config"]
     assert line["value"] > 0 and took < 300, took
