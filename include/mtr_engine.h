@@ -276,7 +276,9 @@ int  mtr_engine_timing_enable (mtr_engine* e, int on);
 int  mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, float* ms_bank, uint32_t* calls);
 /* The same per call, without resetting anything: out [min (calls, cap)][4] = fused, gate, everything behind the gate (bank,
  * integer paths, history), and the whole call from its first to its last event (ms); *calls = timed calls since the last
- * query.  For the median beside the mean (a power-limited kernel drifts within a run).  Synchronises. */
+ * query.  For the median beside the mean (a power-limited kernel drifts within a run).  Synchronises.
+ * (On the host path every CHUNK of mtr_engine_process_host is a timed call: `calls` counts chunks there; a call whose four
+ * events could not all be created is not counted.) */
 int  mtr_engine_timing_calls (mtr_engine* e, float* out, uint32_t cap, uint32_t* calls);
 /* With tune_prune: interpolator tile passes considered / skipped since the engine was created. */
 int  mtr_engine_prune_stats (mtr_engine* e, uint64_t* considered, uint64_t* skipped);

@@ -103,3 +103,46 @@ def test_no_cpu_fallback():
     with pytest.raises(M.EngineError) as ei:
         M.Engine(4)
     assert "(-3)" in str(ei.value) and "no CPU path" in str(ei.value)
+
+
+def test_new_entry_points_reject_what_they_must_without_a_device():
+    """The round-5 additions of the ABI, as far as they go without a GPU: the state-blob helpers are pure, the communicator
+    calls check their arguments before they touch RCCL, and RCCL's version is readable."""
+    assert M.lib.mtr_state_blob_count(None, 0) == 0
+    assert M.lib.mtr_state_blob_count(b"x" * 200, 200) == 0            # not a blob: no magic
+    assert M.lib.mtr_engine_state_bytes(None, 5) == 0
+    assert M.lib.mtr_engine_state_export(None, 0, 1, None, 0) == -1
+    assert M.lib.mtr_engine_state_import(None, 0, None, 0) == -1
+    assert M.lib.mtr_comm_init_timeout(None, 0, 1, None, 0, 1000, None) == -1
+    assert M.lib.mtr_comm_probe(None, 1000, None) == -1 and M.lib.mtr_comm_set_timeout(None, 1000) == -1
+    assert M.engine.rccl_version() >= 21800
+    assert (M.engine.ERR_TIMEOUT, M.engine.ERR_STATE) == (-6, -7)
+
+
+def test_a_timing_only_build_names_itself_and_is_refused(tmp_path):
+    """A library built with -DMTR_TIMING_ONLY_BUILD may carry kernels with a role switched off (tools/: elimination runs — wrong
+    results by construction): mtr_version () says so, and the package refuses to load it unless the caller is a timing tool
+    (MTR_ALLOW_TIMING_ONLY_BUILD=1).  Built here from the engine's host TU alone, linked with the shipped kernels."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    hipcc = "/opt/rocm/bin/hipcc"
+    objdir = os.path.join(root, "meters.lv2_amd", "lib", "obj")
+    if not (os.path.exists(hipcc) and os.path.isdir(objdir) and shutil.which("g++")):
+        pytest.skip("needs hipcc and the built objects (the build container)")
+    obj = str(tmp_path / "mtr_engine_timing.o")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++20", "-fPIC", "-DMTR_TIMING_ONLY_BUILD", "-I" + os.path.join(root, "include"),
+                    "-I" + os.path.join(root, "meters.lv2_amd", "csrc"), "-c", os.path.join(root, "meters.lv2_amd", "csrc", "mtr_engine.hip"), "-o", obj],
+                   check=True, capture_output=True, timeout=600)
+    so = str(tmp_path / "libmtr_engine.so")
+    others = [os.path.join(objdir, f) for f in os.listdir(objdir) if f.endswith(".o") and f != "mtr_engine.o"]
+    subprocess.run(["g++", "-shared", "-fPIC", "-o", so, obj] + others + ["-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lm"],
+                   check=True, capture_output=True, timeout=300)
+    code = "import sys; sys.path.insert(0, %r); import meters.lv2_amd as M; print(M.lib.mtr_version().decode())" % root
+    env = dict(os.environ, MTR_LIB=so)
+    env.pop("MTR_ALLOW_TIMING_ONLY_BUILD", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "TIMING-ONLY build" in r.stderr, (r.stdout, r.stderr[-800:])
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, MTR_ALLOW_TIMING_ONLY_BUILD="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TIMING-ONLY BUILD" in r.stdout, (r.stdout, r.stderr[-800:])
