@@ -836,6 +836,8 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		return fail (MTR_ERR_ARG, "BITSTATS / SIGDIST: n_frames per call must be < 2^31 - 1");
 	if ((e->cfg.meters & MTR_METER_KMETER) && n_frames >= 0x7fffffffull)
 		return fail (MTR_ERR_ARG, "KMETER: n_frames per call must be < 2^31 - 1 (the reference's int n)");
+	if ((e->cfg.meters & MTR_METER_TPBALLIST) && n_frames >= 0x7ffff000ull)
+		return fail (MTR_ERR_ARG, "TPBALLIST: n_frames per call must be < 2^31 - 4096");
 	if ((e->cfg.meters & (MTR_METER_EBU | MTR_METER_TRUEPEAK)) && n_frames >= 0xFFFFFFFFull)
 		return fail (MTR_ERR_ARG, "n_frames per call must be < 2^32 - 1");
 	if (st != e->last_stream && e->queued) {

@@ -15,8 +15,8 @@
 //   * `if (v > z) z += w (v - z)` is z <- max (z, a z + w v) with a = 1 - w: a monotone max-affine map, and maps of
 //     that kind compose.  Two attacks in a row are z <- max (z, a z + c, a^2 z + c'), c = w max (v1, v2), c' = (w a) v1 + w v2:
 //     the intercepts depend on the values only — any lane can form them, for any frame — so what is left ON the chain per
-//     frame and filter is the release (folded into the first pair's slopes), four fused multiply-adds, a multiply and two
-//     v_max3, plus a DPP add and half a v_max3 for m = max (z1 + z2).  Exact in real arithmetic; in f32 a few ulps from the
+//     frame and filter is the release (folded into the first pair's slopes) — a multiply, two PACKED fused multiply-adds (a
+//     pair map's two intercepts sit side by side) and two v_max3 — plus a DPP add and half a v_max3 for m = max (z1 + z2).  Exact in real arithmetic; in f32 a few ulps from the
 //     reference's sequence (tests/test_gpu_parity.py::test_truepeak_ballistics_*: 4e-6 of the value; tools/fuzz_tpb.py).
 //   * the interpolator is the matrix-pipe one of mtr_mfma16_fir.h (samples and taps as two f16 halves, three partial
 //     products, f32 accumulation: within 4e-7 of the exact-f32 chain): a workgroup owns 64 (stream, channel)
@@ -32,15 +32,15 @@
 //     whatever is in flight at every barrier), five chunks ahead of its split, which is two chunks ahead of its products.
 //   * TWELVE WAVES, three per SIMD, each with its own copy of the loop, one barrier per chunk:
 //       waves 0, 1   the chains of columns 0 .. 31 | 32 .. 63: lane = (column, filter), plain f32 (round 4: one wave, both
-//                    filters of 64 columns as packed pairs — eleven instructions per frame on ONE wave; here 8.5 on each of two);
+//                    filters of 64 columns as packed pairs — eleven instructions per frame on ONE wave; here 6.5 on each of two);
 //       waves 2, 3   the split of the same halves: lane = (half of a chunk, column); wave 2 also sends the LDS-DMA;
 //       the rest     a block's products as TWO units — unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1);
 //                    unit B: phases 2 and 3 (12 MFMAs) and the second — whose operands are read one iteration AHEAD, behind
 //                    the MFMAs of the chunk before and under its maps.
-//     What bounds it is what a SIMD can issue per chunk (VALU + matrix pipe busy 84 % of the time): round 5 cut the
-//     workgroup's VALU instructions per chunk from 963 to ~850 while adding a second chain wave, removed the LDS bank
+//     What bounds it is what a SIMD can issue per chunk (VALU + matrix pipe busy ~85 % of the time): round 5 cut the
+//     workgroup's VALU instructions per chunk from 963 to ~725 while adding a second chain wave, removed the LDS bank
 //     conflicts (SQ_LDS_BANK_CONFLICT 1.1e9 -> 1.2e8 per launch) and the LDS latency on every role's critical path.
-//     22.9 -> 18.7 ms per 8192 streams x 10 s (profiles/r05_tpb.md).
+//     22.9 -> 17.9 - 18.6 ms per 8192 streams x 10 s across boxes (profiles/r05_tpb.md).
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
@@ -87,12 +87,13 @@ __device__ unsigned long long g_tpb_prof[16][4];
 namespace {
 
 constexpr int NW = 12;                         // waves 0, 1: the chains of columns 0 .. 31 | 32 .. 63; 2, 3: fetch + split of the same halves;
-                                               // unit A of blocks 0 .. 3 on waves 4, 5, 8, 9, unit B on 6, 7, 10, 11.  Waves of equal w mod 4
-                                               // share a SIMD, and what a SIMD issues per chunk is what bounds the kernel: the chains' two SIMDs
-                                               // carry a chain (~150 VALU instructions) and two A units (6 MFMAs each), the other two a split
-                                               // wave (~60) and two B units (12 MFMAs each).  (A on 4 .. 7 and B on 8 .. 11 — a chain, an A and
-                                               // a B per SIMD — is 1.5 % slower; sixteen waves with the B units moved off the chains' SIMDs
-                                               // balance better and lose it at the barrier: profiles/r05_tpb.md)
+                                               // unit A of blocks 0 .. 3 on waves 4, 5, 8, 6, unit B on 9, 10, 7, 11.  Waves of equal w mod 4
+                                               // share a SIMD, and what a SIMD issues per chunk is what bounds the kernel: SIMD 0 carries a chain
+                                               // (~105 VALU instructions per chunk) and two A units (~45 + 6 MFMAs each), SIMD 1 a chain, an A and
+                                               // a B unit (~48 + 12 MFMAs), SIMD 2 a split wave (~60), an A and a B, SIMD 3 a split wave and two
+                                               // B units.  (A chain, an A and a B on every SIMD, or both chains' SIMDs with two A units, are
+                                               // 0.5 - 1 % slower; sixteen waves with the B units off the chains' SIMDs balance better and
+                                               // lose it at the barrier: profiles/r05_tpb.md)
 constexpr int F = 16;                          // frames per chunk = rows of one MFMA block
 constexpr int NCOL = 64;                       // (stream, channel) columns per workgroup: 32 stereo or 64 mono streams
 constexpr int NSLOT = 6;                       // ring slots of 16 samples per column: the 64-sample window of the chunk in the products and
@@ -132,7 +133,8 @@ __device__ __forceinline__ int f16_place (int q, int rot) { return ((q + rot) & 
 __device__ __forceinline__ float max3f (float a, float b, float c) { return __builtin_fmaxf (__builtin_fmaxf (a, b), c); }
 // max (a, b) / max (|a|, b) as ONE instruction (as a C expression every operand that is not provably quiet costs a canonicalising
 // v_max (x, x) first, and an |x| that is used twice a v_and); a NaN loses, as in fmaxf
-__device__ __forceinline__ float max_plain (float a, float b) { float r; asm ("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+__device__ __forceinline__ float max3_plain (float a, float b, float c) { float r; asm ("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float max_abs_plain (float a, float b) { float r; asm ("v_max_f32 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // the maximum of a value over lanes l and l ^ 32, in both (v_permlane32_swap: the upper half of one operand against the lower of the other)
 __device__ __forceinline__ float max_across_halves (float m)
@@ -173,8 +175,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	unsigned char* const stg = cbuf + 2 * CBUF_B;
 	const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
 	const uint32_t s0 = blockIdx.x * NSTR;
-	const int64_t n_frames = (int64_t) a.n_frames;
-	const int64_t n_chunks = (n_frames + F - 1) / F;
+	// (32-bit: gfx950 has no scalar 64-bit signed compare, and every `t < n_chunks` of every wave and iteration was two or three
+	// VALU instructions — ~80 of a workgroup's ~850 per chunk.  mtr_launch_tpb refuses calls of 2^31 - 4096 frames or more.)
+	const int n_frames = (int) a.n_frames;
+	const int n_chunks = (n_frames + F - 1) / F;
 
 	// ---- the chains (waves 0, 1): lane = (column ci of the wave's 32, filter phi) ------------------------------------------
 	// One filter of one column per lane, in plain f32 — round 4 walked both filters of a column as a packed pair in ONE wave of 64
@@ -229,11 +233,11 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	const uint32_t stg_lds = (uint32_t) (size_t) (__attribute__ ((address_space (3))) unsigned char*) stg;
 	// (as inline assembly: the compiler must not know that these write LDS — it would wait for them, vmcnt (0), in front of
 	// every LDS access and every barrier that follows, and the point is that they stay in flight across three barriers)
-	auto dma = [&] (int64_t j) __attribute__ ((always_inline)) {        // whole chunks only: (j + 1) F <= n_frames; into staging buffer j mod 4
-		const float* const g0 = dsrc[0] + (size_t) j * (F * C);
-		const float* const g1 = dsrc[1] + (size_t) j * (F * C);
-		const float* const g2 = dsrc[2] + (size_t) j * (F * C);
-		const float* const g3 = dsrc[3] + (size_t) j * (F * C);
+	auto dma = [&] (int j) __attribute__ ((always_inline)) {        // whole chunks only: (j + 1) F <= n_frames; into staging buffer j mod 4
+		const float* const g0 = dsrc[0] + (size_t) (uint32_t) j * (F * C);
+		const float* const g1 = dsrc[1] + (size_t) (uint32_t) j * (F * C);
+		const float* const g2 = dsrc[2] + (size_t) (uint32_t) j * (F * C);
+		const float* const g3 = dsrc[3] + (size_t) (uint32_t) j * (F * C);
 		const uint32_t l = stg_lds + (uint32_t) ((int) (j & (NSTG - 1)) * NP) * 1024u;
 		// (m0 — the LDS base of an LDS-DMA — is saved and restored inside the statement: the compiler may keep a value of its own
 		// there, and does not accept m0 on a clobber list; an s_nop between a write of m0 and the instruction that reads it)
@@ -253,7 +257,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		else                   asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
 	};
 	// this lane's eight samples of chunk j: from the staging buffer the LDS-DMA filled ...
-	auto take_staged = [&]<int CH> (int64_t j, float (&x)[8]) __attribute__ ((always_inline)) {
+	auto take_staged = [&]<int CH> (int j, float (&x)[8]) __attribute__ ((always_inline)) {
 		const unsigned char* const b = stg + (int) (j & (NSTG - 1)) * (NP * 1024) + hp * 2048;
 		if (C == 2) {
 #pragma unroll
@@ -275,10 +279,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		// (a column past the batch holds a copy of stream s0's: nothing of it is ever stored — eight selects per chunk saved)
 	};
 	// ... or straight from memory (any chunk, zeros behind the call's last frame)
-	auto take_ragged = [&] (int64_t j, float (&x)[8]) __attribute__ ((always_inline)) {
+	auto take_ragged = [&] (int j, float (&x)[8]) __attribute__ ((always_inline)) {
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
-			const int64_t f = j * F + 8 * hp + i;
+			const int f = j * F + 8 * hp + i;
 			x[i] = (sowner && f < n_frames) ? srow[(size_t) f * C + sch] : 0.f;
 		}
 	};
@@ -354,8 +358,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// A block's products run as TWO units on two waves — unit A: phase 1 (6 MFMAs) and the frame's first pair map (x[n - 24], y1);
 	// unit B: phases 2 and 3 (12 MFMAs) and the second.
 	const int cc = lane & 15, kg = lane >> 4;
-	const bool unit_a = wid >= 4 && !(wid & 2), unit_b = wid >= 4 && (wid & 2);
-	const int blk = (wid & 1) + (wid >= 8 ? 2 : 0);
+	// (unit A of blocks 0 .. 3 on waves 4, 5, 8, 6; unit B on 9, 10, 7, 11 — see NW)
+	const bool unit_a = wid == 4 || wid == 5 || wid == 8 || wid == 6;
+	const bool unit_b = wid == 9 || wid == 10 || wid == 7 || wid == 11;
+	const int blk = wid == 4 ? 0 : wid == 5 ? 1 : wid == 8 ? 2 : wid == 6 ? 3 : wid == 9 ? 0 : wid == 10 ? 1 : wid == 7 ? 2 : 3;
 	const int ucol = 16 * blk + cc;
 	const int urot = f16_rot (ucol);
 	const bool prod_wave = unit_a || unit_b;
@@ -419,6 +425,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		const float xr[4] = { x0.x, x0.y, x0.z, x0.w };
 		const v2f W = v2f{a.w1, a.w2}, WA = v2f{a.w1 * a1, a.w2 * a2};
 		unsigned char* const row = cbuf + par * CBUF_B + ((UB ? F : 0) + 4 * kg) * CROW + blk * 256 + cc * 8;
+		float mprev = 0.f;
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			unsigned char* const cd = row + r * CROW;
@@ -439,8 +446,9 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 			*reinterpret_cast<v2f*> (cd) = v2f{g1x, g2x};                     // filter 1: (c, c')
 			*reinterpret_cast<v2f*> (cd + 128) = v2f{g1y, g2y};               // filter 2
 			// the raw peak (truepeakdsp.cc:65); only the call's ragged last chunk has frames that do not count
-			if (FULL) pk = max_plain (pk, mx);
-			else pk = max_plain (pk, mx * (r < nfl ? 1.f : 0.f));
+			const float mk = FULL ? mx : mx * (r < nfl ? 1.f : 0.f);
+			if (r & 1) pk = max3_plain (pk, mprev, mk);                      // (one v_max3 per two frames)
+			mprev = mk;
 		}
 	};
 
@@ -498,6 +506,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 #define TPB_RD(dst, off) asm volatile ("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(csrc), "n"(off))
 #define TPB_WAIT8(q, b) asm volatile ("s_waitcnt lgkmcnt(0)" : "+v"(q##1[b]), "+v"(q##1[b + 1]), "+v"(q##1[b + 2]), "+v"(q##1[b + 3]), "+v"(q##1[b + 4]), "+v"(q##1[b + 5]), "+v"(q##1[b + 6]), "+v"(q##1[b + 7]), \
 	                                              "+v"(q##2[b]), "+v"(q##2[b + 1]), "+v"(q##2[b + 2]), "+v"(q##2[b + 3]), "+v"(q##2[b + 4]), "+v"(q##2[b + 5]), "+v"(q##2[b + 6]), "+v"(q##2[b + 7]), "+v"(z))
+	const v2f SL12 = v2f{sl1, sl2_}, AP12 = v2f{ap, ap2};
 	auto chain = [&]<bool FULL, int PARITY> (int nf) {
 		constexpr int P = PARITY * CBUF_B;
 		v2f q1[F], q2[F];
@@ -514,10 +523,13 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		for (int f = 0; f < F; ++f) {
 			if (f == 8) TPB_WAIT8 (q, 8);
 			if (FULL || f < nf) {                                            // wave-uniform: only the call's last chunk is short
-				const float u0 = sl0 * z, u1 = __builtin_fmaf (sl1, z, q1[f].x), u2 = __builtin_fmaf (sl2_, z, q1[f].y);
-				const float zh = max3f (u0, u1, u2);
-				const float v1 = __builtin_fmaf (ap, zh, q2[f].x), v2 = __builtin_fmaf (ap2, zh, q2[f].y);
-				z = max3f (zh, v1, v2);
+				// (the two intercepts of a pair map sit side by side, as they were read: ONE packed fused multiply-add per pair map — the
+				// same bits as two plain ones, 6.5 instructions per frame instead of 8.5)
+				const float u0 = sl0 * z;
+				const v2f u12 = __builtin_elementwise_fma (SL12, v2f{z, z}, q1[f]);
+				const float zh = max3f (u0, u12.x, u12.y);
+				const v2f v12 = __builtin_elementwise_fma (AP12, v2f{zh, zh}, q2[f]);
+				z = max3f (zh, v12.x, v12.y);
 				const float zo = __uint_as_float (__builtin_amdgcn_update_dpp (0, __float_as_uint (z), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
 				zm = __builtin_fmaxf (zm, z + zo);                            // z1 + z2 (the same bits in both lanes)
 			}
@@ -529,7 +541,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// its own registers (in ONE loop with the roles as branches the compiler re-fetched the products' twelve tap fragments from
 	// global memory in every iteration).
 	int sw = 0;                                                          // chunk t mod 6: the first slot of its window, and its pieces' base
-	const int64_t n_it = n_chunks + 1;
+	const int n_it = n_chunks + 1;
 	// iterations [t0, t1) of the loop (the parity of an iteration is a compile-time constant in `work`: the buffers it selects)
 	// One iteration.  A column's scale moved when chunk t + 1 was split (last iteration): the three chunks in front of it are split
 	// again and its un follows (`rescale`), in a cold path with its own barrier.  The flag is uniform; its read goes out HERE and is
@@ -537,7 +549,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	// they read ahead, with the split's own data — instead of an LDS round trip at the top of every iteration of every wave.  Every
 	// role asks once and, if the answer is yes, passes the cold barrier once; the split clears the flag behind it.  (PAR = t & 1 and,
 	// for the products, SW = t mod 6 are compile-time constants in `work`: the buffers and ring addresses they select.)
-	auto iteration = [&]<int PAR, int SW> (int64_t t, auto&& work) __attribute__ ((always_inline)) {
+	auto iteration = [&]<int PAR, int SW> (int t, auto&& work) __attribute__ ((always_inline)) {
 		const int flag = flag_sh[PAR];
 		auto moved = [&] () __attribute__ ((always_inline)) { return __builtin_expect (__builtin_amdgcn_readfirstlane (flag) != 0, 0); };
 		PROF_NOW (c0_);
@@ -550,8 +562,8 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	};
 	// iterations [t0, t1) in pairs: what an even iteration reads ahead for the odd one behind it stays in the registers it was loaded
 	// into (with one iteration per trip and the parity as a branch the compiler rotated ~40 registers per trip)
-	auto run_range = [&] (int64_t t0, int64_t t1, auto&& work) __attribute__ ((always_inline)) {
-		int64_t t = t0;
+	auto run_range = [&] (int t0, int t1, auto&& work) __attribute__ ((always_inline)) {
+		int t = t0;
 		if (t < t1 && (t & 1)) { iteration.template operator()<1, -1> (t, work); ++t; }
 		for (; t + 1 < t1; t += 2) {
 			iteration.template operator()<0, -1> (t, work);
@@ -561,7 +573,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	};
 	// ... and all of them in sixes, the ring's period (the products)
 	auto run_six = [&] (auto&& work) __attribute__ ((always_inline)) {
-		int64_t t = 0;
+		int t = 0;
 		for (; t + 5 < n_it; t += 6) {
 			iteration.template operator()<0, 0> (t, work);     iteration.template operator()<1, 1> (t + 1, work);
 			iteration.template operator()<0, 2> (t + 2, work); iteration.template operator()<1, 3> (t + 3, work);
@@ -575,9 +587,9 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	};
 	auto run = [&] (auto&& work) __attribute__ ((always_inline)) { run_range (0, n_it, work); };
 	if (wid < 2) {
-		run ([&]<int PAR, int> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+		run ([&]<int PAR, int> (int t, auto&& moved) __attribute__ ((always_inline)) {
 			if (t >= 1 && !MTR_TPB_DBG_NOCHAIN) {
-				const int64_t left = n_frames - (t - 1) * F;
+				const int left = n_frames - (t - 1) * F;
 				if (left >= F) chain.template operator()<true, PAR ^ 1> (F);
 				else chain.template operator()<false, PAR ^ 1> ((int) left);
 			}
@@ -588,10 +600,10 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		// knows of: any such load makes it count vmcnt, and its conservative waits (vmcnt (0) where paths join) would wait for the
 		// DMA in flight as well.  The second takes over where chunk t + 2 is the call's ragged last one (or for the whole call,
 		// when the streams do not start on 16 bytes) and drains the pipeline.
-		const int64_t n_whole = n_frames / F;
-		const int64_t t_dma = dma_ok && !MTR_TPB_DBG_NOFETCH ? (n_whole > 2 ? n_whole - 2 : 0) : 0;     // chunks 2 .. n_whole - 1 are staged
+		const int n_whole = n_frames / F;
+		const int t_dma = dma_ok && !MTR_TPB_DBG_NOFETCH ? (n_whole > 2 ? n_whole - 2 : 0) : 0;     // chunks 2 .. n_whole - 1 are staged
 		auto staged = [&]<int CH, bool SENDER> () __attribute__ ((always_inline)) {
-			run_range (0, t_dma, [&]<int PAR, int> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+			run_range (0, t_dma, [&]<int PAR, int> (int t, auto&& moved) __attribute__ ((always_inline)) {
 				// chunk t + 5 leaves HBM (into the staging buffer chunk t + 1 was read from, an iteration ago)
 				if (SENDER && (t + AHEAD + 1) * F <= n_frames && !MTR_TPB_DBG_NODMA) dma (t + AHEAD);
 				float x[8];
@@ -613,7 +625,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		};
 		if (wid == 2) staged.template operator()<0, true> ();
 		else          staged.template operator()<C == 2 ? 1 : 0, false> ();
-		run_range (t_dma, n_it, [&]<int PAR, int> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+		run_range (t_dma, n_it, [&]<int PAR, int> (int t, auto&& moved) __attribute__ ((always_inline)) {
 			if (moved ()) { rescale (16 * sw); __syncthreads (); if (lane == 0) flag_sh[PAR] = 0; }
 			if (t + 2 < n_chunks && !MTR_TPB_DBG_NOFETCH) {
 				float x[8];
@@ -633,7 +645,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 #pragma unroll
 			for (int f = 0; f < NF; ++f) asm volatile ("" : "+v"(af[f]));
 			fetch_ops.template operator()<UB, 0> (ops[0]);                  // the first chunk's operands
-			run_six ([&]<int PAR, int SW> (int64_t t, auto&& moved) __attribute__ ((always_inline)) {
+			run_six ([&]<int PAR, int SW> (int t, auto&& moved) __attribute__ ((always_inline)) {
 				if (t < n_chunks && !MTR_TPB_DBG_NOPROD) {
 					m16::f4 y[2];
 					unit_mfma.template operator()<UB> (af, ops[PAR], y);         // on the operands (and the un) read an iteration ago
@@ -645,7 +657,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 					fetch_ops.template operator()<UB, (SW + 1) % NSLOT> (ops[PAR ^ 1]);
 					if ((t + 1) * F <= n_frames) unit_maps.template operator()<UB, true> (PAR, ops[PAR].x0, ops[PAR].un, y, 4);
 					else {
-						const int64_t left = n_frames - t * F - 4 * kg;           // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
+						const int left = n_frames - t * F - 4 * kg;           // this lane's frames are 4 kg .. 4 kg + 3 of the chunk
 						unit_maps.template operator()<UB, false> (PAR, ops[PAR].x0, ops[PAR].un, y, left >= 4 ? 4 : (left > 0 ? (int) left : 0));
 					}
 				} else if (moved ()) __syncthreads ();
@@ -653,7 +665,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 		};
 		if (unit_a)      run_unit.template operator()<false> ();
 		else if (unit_b) run_unit.template operator()<true> ();
-		else run ([&]<int, int> (int64_t, auto&& moved) __attribute__ ((always_inline)) { if (moved ()) __syncthreads (); });   // (idle: keeps the barriers' count)
+		else run ([&]<int, int> (int, auto&& moved) __attribute__ ((always_inline)) { if (moved ()) __syncthreads (); });   // (idle: keeps the barriers' count)
 	}
 #ifdef MTR_TPB_PROF
 	if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 4; ++i) g_tpb_prof[wid][i] = pr[i];
@@ -693,6 +705,7 @@ __global__ void k_history_mono (const float* audio, uint64_t stride, uint64_t n_
 
 int mtr_launch_tpb (const mtr_tpb_args& a, void* stream)
 {
+	if (a.n_frames >= 0x7ffff000ull) return -1;                        // (the kernel counts frames and chunks in 32 bits, a few chunks ahead)
 	static bool raised = false;
 	if (!raised) {
 		(void) hipFuncSetAttribute ((const void*) k_tpb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -7,7 +7,7 @@ for L in "$@"; do
 for m in ebu+tp tp; do
 	out=$top/gpurun_out/clk_${L}_$m
 	rm -rf $out; mkdir -p $out
-	(cd /tmp && MTR_LIB=$top/meters.lv2_amd/$L/libmtr_engine.so rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace -d $out --output-format csv -- python $top/bench.py --no-cpu-baseline --no-extra --steps 4 --warmup 1 --meters $m > $out/log 2>&1)
+	(cd /tmp && MTR_ALLOW_TIMING_ONLY_BUILD=1 MTR_LIB=$top/meters.lv2_amd/$L/libmtr_engine.so rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace -d $out --output-format csv -- python $top/bench.py --no-cpu-baseline --no-extra --steps 4 --warmup 1 --meters $m > $out/log 2>&1)
 	python - <<PY
 import csv, glob, collections, statistics
 dur = collections.defaultdict(list)
