@@ -139,10 +139,24 @@ def committed_traffic(meters, S, T, layout):
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher around it: become `torch.distributed.run --nproc-per-node N bench.py ...`
     (the command the driver itself uses), rendezvous on 127.0.0.1 and a free port.  Rank 0 prints the one JSON line."""
+    import random
     import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
+    # a free port BELOW the kernel's ephemeral range (32768 ..): a port handed out by bind (0) can be given to somebody's outgoing
+    # connection between this probe and the launcher's listen () — seen once on a GPU box: EADDRINUSE, no line
+    port = None
+    for _ in range(64):
+        cand = random.randrange(20000, 32000)
+        with socket.socket() as so:
+            try:
+                so.bind(("127.0.0.1", cand))
+            except OSError:
+                continue
+        port = cand
+        break
+    if port is None:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -610,7 +624,7 @@ def run(args, rank, local, world):
             _, _, bk, w, _ = timed(S, T, M.METER_TPBALLIST, steps=2)
             cfgs["true-peak ballistics (TruePeakdsp::process), 8192 streams x 10 s"] = {
                 "kernel": "k_tpb", "kernel_ms": bk, "wall_ms": w, "frac": frac(S, T, bk),
-                "bound": "what a SIMD can issue per 16-frame chunk: the chains (two waves: lane = (column, filter), 8.5 instructions per frame), the "
+                "bound": "what a SIMD can issue per 16-frame chunk: the chains (two waves: lane = (column, filter), 6.5 instructions per frame), the "
                          "products (two units per block on two waves, operands read an iteration ahead) with their maps, the split (two waves) — "
                          "VALU + matrix pipe busy 84 % of the time, three waves per SIMD, one barrier per chunk (DESIGN.md 3.5)"}
             extra["configs"] = cfgs
