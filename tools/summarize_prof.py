@@ -28,7 +28,7 @@ for f in sorted(glob.glob(src + "/pmc*/**/*counter_collection.csv", recursive=Tr
         acc[k][1] += 1
 kernels = sorted({k[0] for k in acc})
 for kn in kernels:
-    if not any(t in kn for t in ("fused", "gate", "bank", "aggregate", "k_kw", "kwtp", "bitstats", "sigdist", "k_tpb")):
+    if not any(t in kn for t in ("k_seg", "fused", "gate", "bank", "aggregate", "k_kw", "kwtp", "bitstats", "sigdist", "k_tpb")):
         continue
     out += ["### `%s`" % kn, "", "| counter | avg / dispatch |", "|---|---|"]
     for (k, c), (v, n) in sorted(acc.items()):
