@@ -40,7 +40,7 @@
 //     What bounds it is what a SIMD can issue per chunk (VALU + matrix pipe busy ~85 % of the time): round 5 cut the
 //     workgroup's VALU instructions per chunk from 963 to ~725 while adding a second chain wave, removed the LDS bank
 //     conflicts (SQ_LDS_BANK_CONFLICT 1.1e9 -> 1.2e8 per launch) and the LDS latency on every role's critical path.
-//     22.9 -> 17.9 - 18.6 ms per 8192 streams x 10 s across boxes (profiles/r05_tpb.md).
+//     22.9 -> 17.9 - 19.3 ms per 8192 streams x 10 s across boxes (profiles/r05_tpb.md).
 #include <hip/hip_runtime.h>
 
 #include "mtr_internal.h"
