@@ -38,14 +38,43 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_FRAME = 8            # one stereo f32 frame, read once
 
 
-def cpu_baseline(host_audio, fs, budget_s=12.0):
-    """EBU R128 + true-peak of the reference (or the port) on host cores over a bounded sample.
-    host_audio: float32 [n, T, 2] copied from the benchmark buffers. Single thread: the
-    reference's operating mode (one instance on one RT thread)."""
+def host_cpu():
+    """(model string, physical cores this process may run on, logical CPUs) of the host: /proc/cpuinfo + the affinity mask."""
+    model, cores = "unknown", set()
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        allowed = set(range(os.cpu_count() or 1))
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [t.strip() for t in line.split(":", 1)]
+                cur[k] = v
+                if k == "model name" and model == "unknown":
+                    model = v
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except (OSError, ValueError):
+        pass
+    return model, (len(cores) or len(allowed)), len(allowed)
+
+
+def cpu_baseline(host_audio, fs, budget_s=9.0):
+    """EBU R128 + true-peak of the reference (or the port) on host cores over a bounded sample (SURVEY.md 8d ii).
+    host_audio: float32 [n, T, 2] copied from the benchmark buffers.  `value` is a SINGLE thread — the reference's operating
+    mode (one instance on one RT thread) — over EBU R128 process() + process_max() x2; `per_meter` times each meter alone on
+    that thread (EBU / true peak x2 / 30-band bank, frames/s); `all_cores` runs one instance per PHYSICAL core of the host
+    (streams are independent; the foreign calls release the GIL).  About 15 s of wall in all.  A reported baseline, never the target."""
     import numpy as np
     from _oracle import Oracle, Reference, have_reference
     impl, kind = (Reference(), "reference") if have_reference() else (Oracle(), "port")
     n, T = host_audio.shape[0], host_audio.shape[1]
+    model, phys, logical = host_cpu()
     done, t0 = 0, time.perf_counter()
     for s in range(n):
         impl.ebu(host_audio[s], fs, 1024)
@@ -57,25 +86,39 @@ def cpu_baseline(host_audio, fs, budget_s=12.0):
     out = {"value": 2.0 * done * T / dt, "unit": "samples/s", "cores": 1, "kind": kind,
            "sample": f"{done} streams x {T / fs:.0f} s of the benchmark's own buffers, EBU R128 process() + "
                      f"process_max() x2, block 1024, {dt:.1f} s wall",
-           "host_cpus": os.cpu_count()}
-    # The whole host for context (SURVEY.md 8d ii): one instance per thread, streams are independent.  The
-    # foreign calls release the GIL.  Still a reported baseline, not a target.
+           "cpu_model": model, "host_physical_cores": phys, "host_cpus": logical}
+    # each meter alone on the same thread (frames/s = stereo frames/s; true peak = both channels)
+    try:
+        split = {}
+        for name, fn, budget in (("ebu_r128", lambda a: impl.ebu(a, fs, 1024), 1.2), ("truepeak_x2", lambda a: impl.tp(a, fs, 1024), 1.2),
+                                 ("bank_30band", lambda a: impl.spectr(a, fs, 1024), 1.5)):
+            k, t1 = 0, time.perf_counter()
+            while True:
+                fn(host_audio[k % n]); k += 1
+                if time.perf_counter() - t1 > budget:
+                    break
+            split[name] = {"frames_per_s": k * T / (time.perf_counter() - t1), "streams": k}
+        out["per_meter"] = split
+    except Exception as exc:                                  # never let a context figure break the benchmark line
+        out["per_meter"] = {"error": repr(exc)}
     try:
         from concurrent.futures import ThreadPoolExecutor
-        w = max(1, min(os.cpu_count() or 1, 64, n))
+        w = max(1, phys)                                      # one instance per physical core (SURVEY.md 8d ii)
 
         def one(s):
             impl.ebu(host_audio[s], fs, 1024)
             impl.tp(host_audio[s], fs, 1024)
 
-        jobs = [s % n for s in range(max(n, 16 * w))]         # a few seconds of wall time
+        per_stream_s = dt / max(done, 1)
+        rounds = max(1, min(8, int(3.0 / max(per_stream_s, 1e-3))))      # ~3 s of wall: `rounds` streams per thread
+        jobs = [s % n for s in range(rounds * w)]
         t1 = time.perf_counter()
         with ThreadPoolExecutor(w) as ex:
             list(ex.map(one, jobs))
         dm = time.perf_counter() - t1
-        out["all_cores"] = {"value": 2.0 * len(jobs) * T / dm, "threads": w,
-                            "sample": f"{len(jobs)} stream passes over {w} threads, {dm:.1f} s wall"}
-    except Exception as exc:                                  # never let the context figure break the benchmark line
+        out["all_cores"] = {"value": 2.0 * len(jobs) * T / dm, "unit": "samples/s", "threads": w,
+                            "sample": f"{len(jobs)} stream passes over {w} threads (one per physical core), {dm:.1f} s wall"}
+    except Exception as exc:
         out["all_cores"] = {"error": repr(exc)}
     return out
 
@@ -239,6 +282,7 @@ def main():
     ap.add_argument("--fir", type=int, default=0, help="0 auto (mirror-symmetric form), 1 dense 3x48 taps")
     ap.add_argument("--prune", type=int, default=0, help="1 = exact true-peak pruning (identical result, data-dependent speed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tail", type=int, default=0, help="0 auto (deferred for batches), 1 serial (everything on the caller's stream), 2 always deferred")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -329,6 +373,7 @@ def run(args, rank, local, world):
     eng = M.Engine(S, fs, meters, n_channels=1 if mono else 2, device=local, tune_run=args.run,
                    tune_segments=args.segments, tune_layout=args.layout, tune_fir=args.fir, tune_prune=args.prune)
     eng.integr_start()
+    eng.set_deferred_tail(args.tail)
     # The job's communicator: RCCL behind the C ABI.  Every rank is past its allocations and its first kernels, and the ranks
     # AGREE on how they reduce (meters.lv2_amd.dist.agree_on_collective: a vote over the gloo control plane; fallbacks: a
     # torch.distributed NCCL (= RCCL) group, then gloo on the same device buffers — what the shared-GPU rehearsal ends up with).
@@ -400,6 +445,16 @@ def run(args, rank, local, world):
         dist.all_gather(rows, torch.tensor(ranks_ms[0], dtype=torch.float64))
         ranks_ms = [[float(v) for v in r] for r in rows]
 
+    # RCCL's own view of the job's communicator: ranks it holds, the device it bound this rank to (and HIP's ordinal beside it)
+    rccl_nranks = comm.nranks() if comm is not None else None
+    mine_dev = [rank, local, comm.device() if comm is not None else -1]
+    rank_devices = [mine_dev]
+    if world > 1:
+        rows = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor(mine_dev, dtype=torch.int64))
+        rank_devices = [[int(v) for v in r] for r in rows]
+    rank_devices = [{"rank": r[0], "hip_device": r[1], "rccl_device": (r[2] if r[2] >= 0 else None)} for r in rank_devices]
+    deferred_calls = eng.deferred_calls()
     if rank == 0:
         frames_job = float(world) * S * T * args.steps
         ms_step = 1e3 * dt / args.steps
@@ -422,6 +477,12 @@ def run(args, rank, local, world):
                        "streams_per_gpu": S, "frames_per_stream": T, "sample_rate": fs,
                        "frames_per_s": frames_job / dt, "parallelism": f"streams sharded x{world}",
                        "collective": collective, "rccl_version": M.engine.rccl_version(),
+                       # what RCCL itself says about the communicator the reduction ran on (ncclCommCount / ncclCommCuDevice per
+                       # rank): null when the ranks agreed on a fallback — the string above is the host's word, this is RCCL's
+                       "rccl_nranks": rccl_nranks, "rank_devices": rank_devices,
+                       "tail": ("deferred: k_gate + k_aggregate + the all-reduce of step i on the engine's side stream, beside k_seg of step i + 1"
+                                if deferred_calls else "serial: everything on the caller's stream"),
+                       "deferred_calls": deferred_calls,
                        "comm_init_ms": getattr(comm, "init_ms", None), "comm_probe_ms": getattr(comm, "probe_ms", None),
                        "comm_negotiation_ms": negotiation_ms, "comm_timeout_s": comm_timeout_s if world > 1 else None},
         }

@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 1
+/* 2: + mtr_engine_set_deferred_tail / _join / _deferred_stats, mtr_comm_nranks / _device (round 6); the entry points of
+ *    round 5 (mtr_comm_init_timeout, mtr_comm_probe, mtr_comm_set_timeout, mtr_rccl_version, mtr_engine_state_*,
+ *    mtr_state_blob_count, MTR_ERR_TIMEOUT / MTR_ERR_STATE) are what a version-1 library may lack.  A client checks
+ *    mtr_abi_version () >= the version it was written against before it binds anything newer. */
+#define MTR_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 #define MTR_OK               0
@@ -151,8 +155,23 @@ int  mtr_engine_process_planar_host (mtr_engine* e, const float* const* channels
  * host's audio thread costs what every later one does (tests/test_lv2_latency.py) instead of several milliseconds. */
 int  mtr_engine_prepare_host (mtr_engine* e, uint32_t max_block_frames);
 
-/* Wait for everything queued by process calls. */
+/* Wait for everything queued by process calls (on the caller's stream and on the engine's side stream, below). */
 int  mtr_engine_sync (mtr_engine* e);
+
+/* The tail of a process call — the once-per-fragment bookkeeping of Ebu_r128_proc::process (ebu_r128_proc.cc:217-244: k_gate)
+ * and, if mtr_engine_reduce follows, the job's reduction — may run DEFERRED on an engine-owned side stream, beside the
+ * fused kernel of the NEXT call instead of in front of it: that kernel needs the K-filter state and the interpolator history
+ * of this call, never the gate's results.  Same kernels, same inputs, fragments inserted in fragment order: every result is
+ * bit for bit that of the serial order (tests/test_gpu_tail.py).  mode 0 = auto (calls of >= 2^24 stream-frames: a batch),
+ * 1 = never (everything on the caller's stream, as the LV2-sized calls always are), 2 = always.
+ * What a caller must know: results are complete when BOTH streams are — every getter, mtr_engine_sync, state export / import
+ * and the resets wait for both; a caller that reads d_hist / d_max of mtr_engine_reduce (or any engine buffer) in stream
+ * order calls mtr_engine_join (e, stream) first: `stream` then waits for the side stream's work queued so far.
+ * No reference counterpart (the reference is one instance on one thread). */
+int  mtr_engine_set_deferred_tail (mtr_engine* e, int mode);
+int  mtr_engine_join (mtr_engine* e, void* hip_stream);
+/* Process calls whose tail was deferred, since the engine was created. */
+int  mtr_engine_deferred_stats (mtr_engine* e, uint64_t* calls);
 
 /* ---- results (synchronise, then copy to host memory) ----------------------- */
 
@@ -237,8 +256,18 @@ int  mtr_comm_probe (mtr_comm* c, uint32_t timeout_ms, float* ms);
 /* Deadline of the calls mtr_engine_reduce makes on a communicator built by mtr_comm_init_timeout (the enqueue of the
  * collective, not its execution on the stream). */
 int  mtr_comm_set_timeout (mtr_comm* c, uint32_t timeout_ms);
+/* A communicator built with a deadline is finalised (ncclCommFinalize, polled to that deadline) and destroyed — collectives
+ * still queued on a stream complete — and aborted only if that does not happen in time or it had failed before; a blocking
+ * one is ncclCommDestroy'd.  Either way: synchronise the streams mtr_engine_reduce was given (mtr_engine_sync) first. */
 void mtr_comm_destroy (mtr_comm* c);
+/* After a process call whose tail was deferred (above) the aggregate and the all-reduce follow the gate on the engine's side
+ * stream (ordered behind what `hip_stream` holds at the time of the call): d_hist / d_max are complete after
+ * mtr_engine_join (e, hip_stream) in stream order, or mtr_engine_sync for the host. */
 int  mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max, void* hip_stream);
+/* What RCCL itself says about the communicator: ncclCommCount and ncclCommCuDevice (a negative status if it has been
+ * aborted) — so that a job's line can prove the collective ran over N ranks on N devices (bench.py: config.rccl_nranks). */
+int  mtr_comm_nranks (mtr_comm* c);
+int  mtr_comm_device (mtr_comm* c);
 /* ncclGetVersion of the RCCL this process runs (e.g. 22606), or a negative status. */
 int  mtr_rccl_version (void);
 
@@ -259,7 +288,11 @@ void mtr_hist_loudness (const int32_t* hist_M, const int32_t* hist_S,
  * configuration (meters, channels, sample rate; n_streams and the slots may differ) — in another process, on another GPU —
  * and processing continues bit for bit as if it had never stopped (tests/test_gpu_state.py).  An engine that has not
  * processed anything since it was created or reset takes the blob's cursors; any other must stand at the same ones (the
- * streams of an engine advance in lock step), else MTR_ERR_STATE.  Both calls synchronise.
+ * streams of an engine advance in lock step), else MTR_ERR_STATE.  "Takes the blob's cursors" includes integration on / off
+ * and the bank's speed: a fresh engine on which mtr_engine_integr_start or mtr_engine_spectr_set_speed was called before the
+ * import continues with the BLOB's setting (they are part of where the streams stand), not with the setter's.  The blob
+ * carries a checksum of its payload; a blob whose cursors are out of range or whose checksum does not match is refused
+ * with MTR_ERR_STATE and the engine is left as it was.  Both calls synchronise.
  * No reference counterpart: the reference persists one UI word (src/ebulv2.cc:514-553); SURVEY.md 5 (checkpoint / resume). */
 size_t mtr_engine_state_bytes (const mtr_engine* e, uint32_t count);
 int  mtr_engine_state_export (mtr_engine* e, uint32_t first, uint32_t count, void* blob, size_t capacity);

@@ -103,7 +103,29 @@ struct mtr_engine {
 	DevBuf<int32_t>  gate_max;      // [S][2] max-hold scratch of the multi-workgroup gate path
 	DevBuf<float>    fir_hist[2];   // ping-pong 47-frame history
 	int              hist_cur = 0;
-	DevBuf<float>    scan_m, bin_power, tile_power, frag_power, stage;
+	DevBuf<float>    scan_m, bin_power, tile_power[2], frag_power, stage;
+	// The call's tail — k_gate, then the job's reduction (k_aggregate + the RCCL all-reduce) — DEFERRED to an engine-owned side
+	// stream: the fused kernel of call i + 1 needs only what the fused kernel and k_history of call i wrote (K-filter state, FIR
+	// history), never the gate's bookkeeping, so the tail of call i runs beside it instead of in front of it.  tile_power is
+	// double-buffered (the gate of call i reads one while the fused kernel of call i + 1 fills the other); the true-peak fold
+	// moves from the gate into k_history on the caller's stream (tp_call is already being raised by call i + 1).  Results are
+	// bit for bit those of the serial order: same kernels, same inputs, the fragment inserts in fragment order (gates follow
+	// one another on the side stream; ebumeter/ebu_r128_proc.cc:217-244).
+	int              tail_mode = 0;          // 0 auto (calls of >= TAIL_AUTO_FRAMES stream-frames), 1 never, 2 always
+	hipStream_t      tail_stream = nullptr;
+	hipEvent_t       ev_fused = nullptr;     // caller's stream -> side: the call's fused kernels are done
+	hipEvent_t       ev_gate[2] = { nullptr, nullptr };   // side -> caller's: the gate that read tile_power[b] is done
+	bool             gate_pending[2] = { false, false };
+	hipEvent_t       ev_red = nullptr;       // side -> caller's: the reduction that read the peak holds is done (the next fold waits for it)
+	bool             red_pending = false;
+	hipEvent_t       ev_main = nullptr;      // caller's -> side: everything the reduction reads from the caller's stream (the fold) is done
+	hipEvent_t       ev_join = nullptr;
+	bool             tail_pending = false;   // the side stream holds work nobody has waited for yet
+	bool             last_deferred = false;  // the most recent process call deferred its tail: mtr_engine_reduce follows it there
+	int              tp_cur = 0;             // tile_power buffer of the most recent call
+	uint64_t         deferred_calls = 0;
+	uint32_t         tail_gate_grid = 512;   // workgroups of a deferred gate: two per CU (set from the device's CU count)
+	uint32_t         tail_delay_us = 100;    // see process_device: the deferred gate must not be dispatched together with the next fused kernel
 	PlanSlot         plan_slot[PLAN_SLOTS];
 	int              plan_cur = 0;
 	const uint32_t*  tile_start = nullptr;   // into plan_slot[plan_cur].dev
@@ -154,9 +176,12 @@ struct mtr_engine {
 	hipEvent_t       ev_copied[2] = { nullptr, nullptr }, ev_computed[2] = { nullptr, nullptr };
 
 	bool timing = false;
-	std::vector<hipEvent_t> ev;     // groups of 4: start, after fused, after gate, after bank
+	std::vector<hipEvent_t> ev;     // groups of EV_PER_CALL: start, fused end, gate begin, gate end (those two on the stream the gate ran on), rest begin, end
 	uint32_t timed_calls = 0;
 };
+
+constexpr int EV_PER_CALL = 6;
+constexpr uint64_t TAIL_AUTO_FRAMES = 1ull << 24;   // stream-frames per call (134 MB of stereo f32: ~40 us of the fused kernel) from which the tail is deferred
 
 static void mat4_mul (const double* a, const double* b, double* c)
 {
@@ -238,8 +263,41 @@ static int upload_consts (mtr_engine* e)
 	return MTR_OK;
 }
 
+// `st` waits for everything the side stream holds (a serial gate, a reset, the caller's own aggregate behind deferred gates)
+static int join_tail (mtr_engine* e, hipStream_t st)
+{
+	if (!e->tail_pending || !e->tail_stream) return MTR_OK;
+	if (!e->ev_join) HIPCHK (hipEventCreateWithFlags (&e->ev_join, hipEventDisableTiming));
+	HIPCHK (hipEventRecord (e->ev_join, e->tail_stream));
+	HIPCHK (hipStreamWaitEvent (st, e->ev_join, 0));
+	// (only the engine's own stream carries the later calls and the host's waits: a join onto any other stream settles nothing for them)
+	if (st == e->last_stream) { e->tail_pending = false; e->gate_pending[0] = e->gate_pending[1] = false; e->red_pending = false; }
+	return MTR_OK;
+}
+
+// the host waits for the caller's stream and the side stream
+static int sync_all (mtr_engine* e)
+{
+	HIPCHK (hipStreamSynchronize (e->last_stream));
+	if (e->tail_stream && e->tail_pending) {
+		HIPCHK (hipStreamSynchronize (e->tail_stream));
+		e->tail_pending = false; e->gate_pending[0] = e->gate_pending[1] = false; e->red_pending = false;
+	}
+	return MTR_OK;
+}
+
+static int tail_setup (mtr_engine* e)
+{
+	if (e->tail_stream) return MTR_OK;
+	HIPCHK (hipStreamCreateWithFlags (&e->tail_stream, hipStreamNonBlocking));
+	hipEvent_t* evs[] = { &e->ev_fused, &e->ev_gate[0], &e->ev_gate[1], &e->ev_red, &e->ev_main };
+	for (hipEvent_t* v : evs) if (!*v) HIPCHK (hipEventCreateWithFlags (v, hipEventDisableTiming));
+	return MTR_OK;
+}
+
 static int state_init (mtr_engine* e, int what, hipStream_t st)
 {
+	{ const int jrc = join_tail (e, st); if (jrc) return jrc; }       // (a deferred gate may still be writing what this clears)
 	e->queued = true;                // (work on last_stream: a caller that moves to another stream must be ordered behind it)
 	if (mtr_launch_state_init (e->state.p, e->hist.p, e->cfg.n_streams, what, st)) return fail (MTR_ERR_HIP, "k_state_init");
 	return MTR_OK;
@@ -351,8 +409,10 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 	}
 	{
 		hipDeviceProp_t pr;
-		if (hipGetDeviceProperties (&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) e->seg_slots = 4u * (uint32_t) pr.multiProcessorCount;
+		if (hipGetDeviceProperties (&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) { e->seg_slots = 4u * (uint32_t) pr.multiProcessorCount; e->tail_gate_grid = 2u * (uint32_t) pr.multiProcessorCount; }
 	}
+	if (const char* v = getenv ("MTR_TAIL_DELAY_US")) e->tail_delay_us = (uint32_t) atoi (v);
+	if (const char* v = getenv ("MTR_TAIL_GATE_GRID")) e->tail_gate_grid = (uint32_t) atoi (v);   // (tools/r06_tail_probe.py: the experiment behind the default)
 	e->fragm = (uint32_t) ((int) cfg->sample_rate / 20);     // ebu_r128_proc.cc:170
 	e->frcnt = e->fragm;
 	mtr_setup_kweight (cfg->sample_rate, e->kw);
@@ -401,8 +461,13 @@ void mtr_engine_destroy (mtr_engine* e)
 	(void) hipSetDevice (e->cfg.device);
 	(void) hipDeviceSynchronize ();
 	for (hipEvent_t ev : e->ev) (void) hipEventDestroy (ev);
+	{
+		hipEvent_t evs[] = { e->ev_fused, e->ev_gate[0], e->ev_gate[1], e->ev_red, e->ev_main, e->ev_join };
+		for (hipEvent_t v : evs) if (v) (void) hipEventDestroy (v);
+		if (e->tail_stream) (void) hipStreamDestroy (e->tail_stream);
+	}
 	e->state.release (); e->hist.release (); e->fir_hist[0].release (); e->fir_hist[1].release ();
-	e->scan_m.release (); e->bin_power.release (); e->tile_power.release (); e->frag_power.release ();
+	e->scan_m.release (); e->bin_power.release (); e->tile_power[0].release (); e->tile_power[1].release (); e->frag_power.release ();
 	e->stage.release ();
 	for (PlanSlot& ps : e->plan_slot) { ps.dev.release (); ps.pin.release (); if (ps.done) (void) hipEventDestroy (ps.done); }
 	e->pin_in.release (); e->pin_state.release (); e->pin_bank.release ();
@@ -442,6 +507,7 @@ int mtr_engine_reset (mtr_engine* e)
 	e->advanced = false;
 	e->hist_cur = 0;
 	e->last_n_frag = 0;
+	e->last_deferred = false;
 	if (e->cfg.meters & MTR_METER_DR14) { const int drc = mtr_engine_dr14_reset (e); if (drc) return drc; }
 	if (e->cfg.meters & MTR_METER_KMETER) { const int krc = mtr_engine_kmeter_reset (e); if (krc) return krc; e->km_fpp = 0; e->km_fall = 0.f; }
 	if (e->cfg.meters & (MTR_METER_BITSTATS | MTR_METER_SIGDIST)) return mtr_engine_intstat_reset (e);
@@ -778,7 +844,9 @@ static int build_plan (mtr_engine* e, uint64_t N, uint32_t head, uint32_t body_t
 
 	// (with head-room: an LV2 host's blocks see a fragment end in some calls and none in others, and a buffer that grows
 	// by one word then is a hipMalloc — 0.3 ms — in the audio thread)
-	if (e->tile_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_tiles, 16))
+	// (a buffer that grows is freed first, and hipFree waits for the device: no deferred gate still reads it)
+	if (e->tile_power[0].reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_tiles, 16))
+	    || e->tile_power[1].reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_tiles, 16))
 	    || e->frag_power.reserve ((size_t) e->cfg.n_streams * std::max<uint32_t> (n_frag, 16)))
 		return fail (MTR_ERR_NOMEM, "hipMalloc plan buffers");
 	// the next slot of the ring; its previous contents were last read PLAN_SLOTS plans ago
@@ -856,8 +924,15 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	const bool bank = e->cfg.meters & MTR_METER_SPECTR30;
 
 	const bool tm = e->timing && e->timed_calls < 4096;
-	const size_t ev0 = (size_t) e->timed_calls * 4;
+	const size_t ev0 = (size_t) e->timed_calls * EV_PER_CALL;
 	if (tm) { hipEvent_t v = next_event (e, ev0); if (v) HIPCHK (hipEventRecord (v, st)); }
+
+	// the tail of this call (k_gate; the job's reduction if mtr_engine_reduce follows) on the side stream?
+	const bool defer = (ebu || tp) && (e->tail_mode == 2 || (e->tail_mode == 0 && (uint64_t) S * n_frames >= TAIL_AUTO_FRAMES));
+	if (defer) { const int trc = tail_setup (e); if (trc) return trc; }
+	else if (ebu || tp) { const int jrc = join_tail (e, st); if (jrc) return jrc; }   // a serial gate follows the deferred ones
+	e->last_deferred = defer;
+	bool fold_in_history = false;
 
 	if (ebu || tp) {
 		const PlanCtx pctx = plan_ctx (e);
@@ -869,7 +944,12 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		fa.audio = d_audio; fa.stride = stride;
 		fa.hist = e->fir_hist[e->hist_cur].p + vo * MTR_FIR_HALO * 2;
 		fa.tile_start = e->tile_start; fa.seg_tile = e->seg_tile; fa.scan_m = e->scan_m.p;
-		fa.state = e->state.p + vo; fa.tile_power = e->tile_power.p + vo * pl.n_tiles;
+		// (deferred: the other tile_power buffer than the previous call's, whose gate may still be reading; the gate that read
+		// this one two calls ago must be through — it has been for a whole call)
+		const int tb = defer ? (e->tp_cur ^ 1) : 0;
+		if (defer && e->gate_pending[tb]) { HIPCHK (hipStreamWaitEvent (st, e->ev_gate[tb], 0)); e->gate_pending[tb] = false; }
+		e->tp_cur = tb;
+		fa.state = e->state.p + vo; fa.tile_power = e->tile_power[tb].p + vo * pl.n_tiles;
 		fa.n_streams = S; fa.n_segs = pl.n_segs; fa.n_tiles = pl.n_tiles;
 		fa.warm_tiles = (uint32_t) std::ceil (MTR_WARM_SEC * e->cfg.sample_rate / (float) (64 * e->run));
 		fa.a0 = e->kw[0]; fa.a1 = e->kw[1]; fa.a2 = e->kw[2]; fa.b1 = e->kw[3]; fa.b2 = e->kw[4];
@@ -915,6 +995,22 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		if (lrc) { plan_abort (e, st); return fail (MTR_ERR_HIP, "k_fused launch", hipGetLastError ()); }
 		if (tm) { hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st)); }
 
+		hipStream_t gst = st;                                          // the stream the gate runs on
+		if (defer) {
+			gst = e->tail_stream;
+			HIPCHK (hipEventRecord (e->ev_fused, st));
+			HIPCHK (hipStreamWaitEvent (gst, e->ev_fused, 0));
+			// The gate becomes runnable at the very moment the NEXT call's fused kernel does (both wait for this call's), and
+			// its 8192 workgroups would flood the CUs while k_seg's 1024 one-wave workgroups are being placed, one per SIMD:
+			// measured, k_seg then takes 15.4 ms instead of 9.5 (profiles/r06_tail.md) — the placement of a persistent kernel
+			// is for good.  So the side stream first idles for tail_delay_us: by then k_seg is resident (its dispatch takes
+			// ~10 us) and the gate's waves (72 VGPRs) fill in beside it (344 of 512).  Off the critical path by construction.
+			if (e->tail_delay_us && mtr_launch_delay (e->tail_delay_us, gst)) return fail (MTR_ERR_HIP, "k_delay launch");
+			e->tail_pending = true;
+			e->deferred_calls++;
+			fold_in_history = tp;
+		}
+		if (tm) { hipEvent_t v = next_event (e, ev0 + 2); if (v) HIPCHK (hipEventRecord (v, gst)); }
 		mtr_gate_args ga;
 		ga.state = e->state.p + vo; ga.hist = e->hist.p + vo * 2 * MTR_HIST_LEN; ga.tile_power = fa.tile_power;
 		ga.frag_tile = e->frag_tile; ga.frag_power = e->frag_power.p + vo * pl.n_frag; ga.bin_power = e->bin_power.p;
@@ -922,18 +1018,22 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 		ga.tail_tile = ebu ? pl.tail_tile : 0;
 		ga.fragm = (float) e->fragm; ga.integr = e->integr ? 1 : 0;
 		ga.max_scratch = e->gate_max.p + vo * 2;
-		if (mtr_launch_gate (ga, st)) { plan_abort (e, st); return fail (MTR_ERR_HIP, "k_gate launch"); }
+		ga.fold_tp = fold_in_history ? 0 : 1;
+		ga.polite_grid = defer ? e->tail_gate_grid : 0;
+		if (mtr_launch_gate (ga, gst)) { plan_abort (e, gst); return fail (MTR_ERR_HIP, "k_gate launch"); }
+		if (tm) { hipEvent_t v = next_event (e, ev0 + 3); if (v) HIPCHK (hipEventRecord (v, gst)); }
 		{
 			PlanSlot& ps = e->plan_slot[e->plan_cur];                 // k_gate is the plan's last reader
-			HIPCHK (hipEventRecord (ps.done, st));
+			HIPCHK (hipEventRecord (ps.done, gst));
 			ps.pending = true;
 		}
+		if (defer) { HIPCHK (hipEventRecord (e->ev_gate[tb], gst)); e->gate_pending[tb] = true; }
 		e->last_n_frag = ga.n_frag;
 		e->frcnt = pl.frcnt_out;
 	} else if (tm) {
-		hipEvent_t v = next_event (e, ev0 + 1); if (v) HIPCHK (hipEventRecord (v, st));
+		for (int k = 1; k <= 3; ++k) { hipEvent_t v = next_event (e, ev0 + k); if (v) HIPCHK (hipEventRecord (v, st)); }
 	}
-	if (tm) { hipEvent_t v = next_event (e, ev0 + 2); if (v) HIPCHK (hipEventRecord (v, st)); }
+	if (tm) { hipEvent_t v = next_event (e, ev0 + 4); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 	if (bank) {
 		mtr_bank_args ba;
@@ -996,15 +1096,18 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	}
 	if (tp || tpb) {
 		// the 47 frames before the next call; after every consumer of the current history
+		// (deferred: the fold of this call's peaks rides here — behind the reduction of the previous call, which reads the holds)
+		if (fold_in_history && e->red_pending) { HIPCHK (hipStreamWaitEvent (st, e->ev_red, 0)); e->red_pending = false; }
 		const int hrc = e->cfg.n_channels == 2
-			? mtr_launch_history (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p + vo * MTR_FIR_HALO * 2, e->fir_hist[e->hist_cur ^ 1].p + vo * MTR_FIR_HALO * 2, S, st)
+			? mtr_launch_history (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p + vo * MTR_FIR_HALO * 2, e->fir_hist[e->hist_cur ^ 1].p + vo * MTR_FIR_HALO * 2, S,
+			                      fold_in_history ? e->state.p + vo : nullptr, st)
 			: mtr_launch_history_mono (d_audio, stride, n_frames, e->fir_hist[e->hist_cur].p + vo * MTR_FIR_HALO * 2, e->fir_hist[e->hist_cur ^ 1].p + vo * MTR_FIR_HALO * 2, S, st);
 		if (hrc) return fail (MTR_ERR_HIP, "k_history launch");
 		e->hist_cur ^= 1;
 	}
 	if (tm) {
-		hipEvent_t v = next_event (e, ev0 + 3);
-		if (v) { HIPCHK (hipEventRecord (v, st)); e->timed_calls++; }      // (a call without its four events is not a timed call)
+		hipEvent_t v = next_event (e, ev0 + 5);
+		if (v) { HIPCHK (hipEventRecord (v, st)); e->timed_calls++; }      // (a call without all of its events is not a timed call)
 	}
 	return MTR_OK;
 }
@@ -1128,6 +1231,7 @@ int mtr_engine_process_planar_host (mtr_engine* e, const float* const* ch, uint3
 	HIPCHK (hipMemcpyAsync (e->stage.p, il, total * sizeof (float), hipMemcpyHostToDevice, st));
 	rc = mtr_engine_process_device (e, e->stage.p, n_frames, n_frames, st);
 	if (rc) return rc;
+	{ const int jrc = join_tail (e, st); if (jrc) return jrc; }     // (a deferred gate — tail mode 2 only, at this size — writes the state copied next)
 	HIPCHK (hipMemcpyAsync (e->pin_state.p, e->state.p, sizeof (mtr_stream_state), hipMemcpyDeviceToHost, st));
 	if (e->cfg.meters & MTR_METER_SPECTR30) {
 		HIPCHK (hipMemcpyAsync (e->pin_bank.p, e->bank_val.p, MTR_NBANDS * sizeof (float), hipMemcpyDeviceToHost, st));
@@ -1156,7 +1260,27 @@ int mtr_engine_sync (mtr_engine* e)
 {
 	if (!e) return fail (MTR_ERR_ARG, "null engine");
 	HIPCHK (hipSetDevice (e->cfg.device));
-	HIPCHK (hipStreamSynchronize (e->last_stream));
+	return sync_all (e);
+}
+
+int mtr_engine_set_deferred_tail (mtr_engine* e, int mode)
+{
+	if (!e || mode < 0 || mode > 2) return fail (MTR_ERR_ARG, "mtr_engine_set_deferred_tail: mode must be 0 (auto), 1 (never) or 2 (always)");
+	e->tail_mode = mode;
+	return MTR_OK;
+}
+
+int mtr_engine_join (mtr_engine* e, void* hip_stream)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	HIPCHK (hipSetDevice (e->cfg.device));
+	return join_tail (e, (hipStream_t) hip_stream);
+}
+
+int mtr_engine_deferred_stats (mtr_engine* e, uint64_t* calls)
+{
+	if (!e) return fail (MTR_ERR_ARG, "null engine");
+	if (calls) *calls = e->deferred_calls;
 	return MTR_OK;
 }
 
@@ -1267,6 +1391,7 @@ int mtr_engine_aggregate_device (mtr_engine* e, int32_t* d_hist, float* d_max, v
 {
 	if (!e || !d_hist || !d_max) return fail (MTR_ERR_ARG, "mtr_engine_aggregate_device: null argument");
 	HIPCHK (hipSetDevice (e->cfg.device));
+	{ const int jrc = join_tail (e, (hipStream_t) hip_stream); if (jrc) return jrc; }   // behind the deferred gates: it reads what they write
 	if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, d_hist, d_max, hip_stream))
 		return fail (MTR_ERR_HIP, "k_aggregate launch");
 	return MTR_OK;
@@ -1399,7 +1524,24 @@ void mtr_comm_destroy (mtr_comm* c)
 {
 	if (!c) return;
 	(void) hipSetDevice (c->device);
-	if (c->comm) (void) (c->nonblocking ? ncclCommAbort (c->comm) : ncclCommDestroy (c->comm));   // (no second deadline at the exit: abort frees without a handshake)
+	if (c->comm && !c->nonblocking) (void) ncclCommDestroy (c->comm);
+	else if (c->comm) {
+		// a healthy communicator with a deadline: finalise (collectives still queued complete), polled to the deadline, then
+		// destroy; abort only if that does not happen in time (abort kills a reduce that is still queued)
+		const auto t0 = std::chrono::steady_clock::now ();
+		const uint32_t limit = c->timeout_ms ? c->timeout_ms : 10000u;
+		ncclResult_t r = ncclCommFinalize (c->comm);
+		bool ok = r == ncclSuccess || r == ncclInProgress;
+		while (ok) {
+			ncclResult_t state = ncclSuccess;
+			if (ncclCommGetAsyncError (c->comm, &state) != ncclSuccess || (state != ncclSuccess && state != ncclInProgress)) { ok = false; break; }
+			if (state == ncclSuccess) break;
+			if (ms_since (t0) >= (double) limit) { ok = false; break; }
+			std::this_thread::sleep_for (std::chrono::microseconds (200));
+		}
+		if (ok) (void) ncclCommDestroy (c->comm); else (void) ncclCommAbort (c->comm);
+	}
+	c->comm = nullptr;
 	if (c->probe_buf) (void) hipFree (c->probe_buf);
 	if (c->probe_stream) (void) hipStreamDestroy (c->probe_stream);
 	delete c;
@@ -1410,10 +1552,12 @@ int mtr_comm_probe (mtr_comm* c, uint32_t timeout_ms, float* ms)
 	if (ms) *ms = 0.f;
 	if (!c) return fail (MTR_ERR_ARG, "mtr_comm_probe: null communicator");
 	if (!c->comm) return fail (MTR_ERR_ARG, "mtr_comm_probe: the communicator has been aborted");
-	HIPCHK (hipSetDevice (c->device));
+	// (every failure from here on leaves the communicator aborted, as the header says)
+#define PROBECHK(call) do { hipError_t he_ = (call); if (he_ != hipSuccess) { comm_abort (c); return fail (MTR_ERR_HIP, #call, he_); } } while (0)
+	PROBECHK (hipSetDevice (c->device));
 	const int32_t one = 1;
-	HIPCHK (hipMemcpyAsync (c->probe_buf, &one, sizeof (one), hipMemcpyHostToDevice, c->probe_stream));
-	HIPCHK (hipStreamSynchronize (c->probe_stream));
+	PROBECHK (hipMemcpyAsync (c->probe_buf, &one, sizeof (one), hipMemcpyHostToDevice, c->probe_stream));
+	PROBECHK (hipStreamSynchronize (c->probe_stream));
 	const auto t0 = std::chrono::steady_clock::now ();
 	const ncclResult_t r = ncclAllReduce (c->probe_buf, c->probe_buf, 1, ncclInt32, ncclSum, c->comm, c->probe_stream);
 	if (r != ncclSuccess && r != ncclInProgress) { comm_abort (c); return nccl_fail ("ncclAllReduce (probe)", r); }
@@ -1435,7 +1579,8 @@ int mtr_comm_probe (mtr_comm* c, uint32_t timeout_ms, float* ms)
 	}
 	if (ms) *ms = (float) ms_since (t0);
 	int32_t got = 0;
-	HIPCHK (hipMemcpy (&got, c->probe_buf, sizeof (got), hipMemcpyDeviceToHost));
+	PROBECHK (hipMemcpy (&got, c->probe_buf, sizeof (got), hipMemcpyDeviceToHost));
+#undef PROBECHK
 	if (got != c->world) {
 		char buf[160];
 		snprintf (buf, sizeof (buf), "mtr_comm_probe: all-reduce of ones over %d ranks gave %d", c->world, (int) got);
@@ -1445,14 +1590,47 @@ int mtr_comm_probe (mtr_comm* c, uint32_t timeout_ms, float* ms)
 	return MTR_OK;
 }
 
+int mtr_comm_nranks (mtr_comm* c)
+{
+	if (!c) return fail (MTR_ERR_ARG, "mtr_comm_nranks: null communicator");
+	if (!c->comm) return fail (MTR_ERR_ARG, "mtr_comm_nranks: the communicator has been aborted");
+	int n = 0;
+	const ncclResult_t r = ncclCommCount (c->comm, &n);
+	if (r != ncclSuccess) return nccl_fail ("ncclCommCount", r);
+	return n;
+}
+
+int mtr_comm_device (mtr_comm* c)
+{
+	if (!c) return fail (MTR_ERR_ARG, "mtr_comm_device: null communicator");
+	if (!c->comm) return fail (MTR_ERR_ARG, "mtr_comm_device: the communicator has been aborted");
+	int d = -1;
+	const ncclResult_t r = ncclCommCuDevice (c->comm, &d);
+	if (r != ncclSuccess) return nccl_fail ("ncclCommCuDevice", r);
+	return d;
+}
+
 int mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max, void* hip_stream)
 {
 	if (!e || !c || !d_hist || !d_max) return fail (MTR_ERR_ARG, "mtr_engine_reduce: null argument");
 	if (!c->comm) return fail (MTR_ERR_ARG, "mtr_engine_reduce: the communicator has been aborted");
 	if (c->device != e->cfg.device) return fail (MTR_ERR_ARG, "mtr_engine_reduce: engine and communicator sit on different devices");
-	int rc = mtr_engine_aggregate_device (e, d_hist, d_max, hip_stream);
-	if (rc) return rc;
 	hipStream_t st = (hipStream_t) hip_stream;
+	const bool deferred = e->last_deferred && e->tail_stream;
+	if (deferred) {
+		// behind the deferred gate, on the side stream: the aggregate reads what the gate wrote there and what the caller's stream
+		// has written up to now (the fold of the call's peaks in k_history); d_hist / d_max are valid after mtr_engine_join /
+		// mtr_engine_sync.  The next call's fold waits for ev_red.
+		HIPCHK (hipSetDevice (e->cfg.device));
+		HIPCHK (hipEventRecord (e->ev_main, st));
+		HIPCHK (hipStreamWaitEvent (e->tail_stream, e->ev_main, 0));
+		st = e->tail_stream;
+		e->tail_pending = true;
+		if (mtr_launch_aggregate (e->state.p, e->hist.p, e->cfg.n_streams, d_hist, d_max, st)) return fail (MTR_ERR_HIP, "k_aggregate launch");
+	} else {
+		const int rc = mtr_engine_aggregate_device (e, d_hist, d_max, hip_stream);
+		if (rc) return rc;
+	}
 	// one group: RCCL launches the sum and the max together (6 KB + 16 B: both are pure latency on xGMI)
 	const auto t0 = std::chrono::steady_clock::now ();
 	ncclResult_t r = ncclGroupStart ();
@@ -1462,8 +1640,9 @@ int mtr_engine_reduce (mtr_engine* e, mtr_comm* c, int32_t* d_hist, float* d_max
 	r = ncclGroupEnd ();
 	if (r1 != ncclSuccess && r1 != ncclInProgress) return nccl_fail ("ncclAllReduce (histograms)", r1);
 	if (r2 != ncclSuccess && r2 != ncclInProgress) return nccl_fail ("ncclAllReduce (peaks)", r2);
-	if (r == ncclInProgress && c->nonblocking) return comm_wait (c, c->timeout_ms, t0, "ncclGroupEnd (mtr_engine_reduce)");
-	if (r != ncclSuccess) return nccl_fail ("ncclGroupEnd", r);
+	if (r == ncclInProgress && c->nonblocking) { const int rc = comm_wait (c, c->timeout_ms, t0, "ncclGroupEnd (mtr_engine_reduce)"); if (rc) return rc; }
+	else if (r != ncclSuccess) return nccl_fail ("ncclGroupEnd", r);
+	if (deferred) { HIPCHK (hipEventRecord (e->ev_red, st)); e->red_pending = true; }
 	return MTR_OK;
 }
 
@@ -1480,9 +1659,17 @@ struct StateHeader {
 	uint32_t frcnt, integr;
 	float    omega;
 	uint64_t dr_scnt;
+	uint64_t payload_fnv;       // FNV-1a (64 bit) of everything behind the header: a checkpoint file that rotted is refused, not trusted
 };
 constexpr uint32_t STATE_MAGIC = 0x5352544du;   // "MTRS"
-constexpr uint32_t STATE_VERSION = 1;
+constexpr uint32_t STATE_VERSION = 2;           // 2: + payload_fnv
+
+uint64_t fnv1a64 (const unsigned char* p, size_t n)
+{
+	uint64_t h = 0xcbf29ce484222325ull;
+	for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+	return h;
+}
 
 struct StateSection { const void* base; size_t elem; };   // a per-stream array: `elem` bytes per stream
 
@@ -1551,12 +1738,14 @@ int mtr_engine_state_export (mtr_engine* e, uint32_t first, uint32_t count, void
 	h.meters = e->cfg.meters; h.n_channels = e->cfg.n_channels; h.sample_rate = e->cfg.sample_rate;
 	h.count = count; h.per_stream_bytes = (uint32_t) state_per_stream (e); h.stream_state_bytes = sizeof (mtr_stream_state);
 	h.frcnt = e->frcnt; h.integr = e->integr ? 1u : 0u; h.omega = e->omega; h.dr_scnt = e->dr_scnt;
-	memcpy (blob, &h, sizeof (h));
-	unsigned char* o = static_cast<unsigned char*> (blob) + sizeof (h);
+	unsigned char* const o0 = static_cast<unsigned char*> (blob) + sizeof (h);
+	unsigned char* o = o0;
 	for (const StateSection& s : state_sections (e)) {
 		if (count) HIPCHK (hipMemcpy (o, static_cast<const unsigned char*> (s.base) + (size_t) first * s.elem, (size_t) count * s.elem, hipMemcpyDeviceToHost));
 		o += (size_t) count * s.elem;
 	}
+	h.payload_fnv = fnv1a64 (o0, (size_t) (o - o0));
+	memcpy (blob, &h, sizeof (h));
 	return MTR_OK;
 }
 
@@ -1575,20 +1764,31 @@ int mtr_engine_state_import (mtr_engine* e, uint32_t first, const void* blob, si
 	if (bytes < sizeof (h) + (size_t) h.count * h.per_stream_bytes) return fail (MTR_ERR_STATE, "mtr_engine_state_import: truncated blob");
 	int rc = check_range (e, first, h.count);
 	if (rc) return rc;
-	// the streams of an engine advance in lock step: a fresh engine takes the blob's cursors, any other must stand at the same ones
-	if (!e->advanced) {
-		e->frcnt = h.frcnt; e->integr = h.integr != 0; e->omega = h.omega; e->dr_scnt = h.dr_scnt;
-		e->plan.valid = false;
-		e->advanced = true;
-	} else if (e->frcnt != h.frcnt || e->integr != (h.integr != 0) || e->omega != h.omega || e->dr_scnt != h.dr_scnt)
+	// the cursors go straight into the tiling of the next call, the payload's ring indices and counters into the kernels:
+	// nothing of a blob is trusted before it has been checked
+	if (h.frcnt == 0 || h.frcnt > e->fragm) return fail (MTR_ERR_STATE, "mtr_engine_state_import: corrupt blob (frames left in the open fragment)");
+	if (h.integr > 1 || !(h.omega > 0.f && h.omega < 1.f)) return fail (MTR_ERR_STATE, "mtr_engine_state_import: corrupt blob (integration flag / bank speed)");
+	if (h.dr_scnt > (uint64_t) rintf (e->cfg.sample_rate * 3.0f)) return fail (MTR_ERR_STATE, "mtr_engine_state_import: corrupt blob (open DR-14 window)");
+	const unsigned char* const i0 = static_cast<const unsigned char*> (blob) + sizeof (h);
+	if (fnv1a64 (i0, (size_t) h.count * h.per_stream_bytes) != h.payload_fnv) return fail (MTR_ERR_STATE, "mtr_engine_state_import: corrupt blob (checksum of the payload)");
+	// the streams of an engine advance in lock step: a fresh engine takes the blob's cursors — integration on / off and the bank's
+	// speed included, whatever integr_start / spectr_set_speed said before: they are part of where the streams stand — any other
+	// must stand at the same ones
+	const bool fresh = !e->advanced;
+	if (!fresh && (e->frcnt != h.frcnt || e->integr != (h.integr != 0) || e->omega != h.omega || e->dr_scnt != h.dr_scnt))
 		return fail (MTR_ERR_STATE, "mtr_engine_state_import: the engine does not stand where the blob's streams do (fragment phase, integration, bank speed or DR-14 window)");
 	rc = mtr_engine_sync (e);
 	if (rc) return rc;
 	e->snap_valid = false;
-	const unsigned char* i = static_cast<const unsigned char*> (blob) + sizeof (h);
+	const unsigned char* i = i0;
 	for (const StateSection& s : state_sections (e)) {
 		if (h.count) HIPCHK (hipMemcpy (const_cast<unsigned char*> (static_cast<const unsigned char*> (s.base)) + (size_t) first * s.elem, i, (size_t) h.count * s.elem, hipMemcpyHostToDevice));
 		i += (size_t) h.count * s.elem;
+	}
+	if (fresh) {                                                 // (only now: a failed sync or copy has not moved the engine)
+		e->frcnt = h.frcnt; e->integr = h.integr != 0; e->omega = h.omega; e->dr_scnt = h.dr_scnt;
+		e->plan.valid = false;
+		e->advanced = true;
 	}
 	return MTR_OK;
 }
@@ -1675,11 +1875,12 @@ int mtr_engine_timing_query (mtr_engine* e, float* ms_fused, float* ms_gate, flo
 	int rc = mtr_engine_sync (e);
 	if (rc) return rc;
 	float f = 0, g = 0, b = 0;
-	for (uint32_t i = 0; i < e->timed_calls && (size_t) i * 4 + 3 < e->ev.size (); ++i) {
+	for (uint32_t i = 0; i < e->timed_calls && (size_t) i * EV_PER_CALL + EV_PER_CALL - 1 < e->ev.size (); ++i) {
 		float t;
-		if (hipEventElapsedTime (&t, e->ev[i * 4], e->ev[i * 4 + 1]) == hipSuccess) f += t;
-		if (hipEventElapsedTime (&t, e->ev[i * 4 + 1], e->ev[i * 4 + 2]) == hipSuccess) g += t;
-		if (hipEventElapsedTime (&t, e->ev[i * 4 + 2], e->ev[i * 4 + 3]) == hipSuccess) b += t;
+		hipEvent_t* const v = &e->ev[(size_t) i * EV_PER_CALL];
+		if (hipEventElapsedTime (&t, v[0], v[1]) == hipSuccess) f += t;
+		if (hipEventElapsedTime (&t, v[2], v[3]) == hipSuccess) g += t;
+		if (hipEventElapsedTime (&t, v[4], v[5]) == hipSuccess) b += t;
 	}
 	if (ms_fused) *ms_fused = f;
 	if (ms_gate) *ms_gate = g;
@@ -1695,11 +1896,12 @@ int mtr_engine_timing_calls (mtr_engine* e, float* out, uint32_t cap, uint32_t* 
 	int rc = mtr_engine_sync (e);
 	if (rc) return rc;
 	if (calls) *calls = e->timed_calls;
-	for (uint32_t i = 0; i < e->timed_calls && i < cap && (size_t) i * 4 + 3 < e->ev.size (); ++i) {
+	for (uint32_t i = 0; i < e->timed_calls && i < cap && (size_t) i * EV_PER_CALL + EV_PER_CALL - 1 < e->ev.size (); ++i) {
 		float* o = out + (size_t) i * 4;
+		hipEvent_t* const v = &e->ev[(size_t) i * EV_PER_CALL];
 		for (int k = 0; k < 3; ++k)
-			if (hipEventElapsedTime (&o[k], e->ev[i * 4 + k], e->ev[i * 4 + k + 1]) != hipSuccess) o[k] = 0.f;
-		if (hipEventElapsedTime (&o[3], e->ev[i * 4], e->ev[i * 4 + 3]) != hipSuccess) o[3] = 0.f;
+			if (hipEventElapsedTime (&o[k], v[2 * k], v[2 * k + 1]) != hipSuccess) o[k] = 0.f;
+		if (hipEventElapsedTime (&o[3], v[0], v[5]) != hipSuccess) o[3] = 0.f;     // (on the caller's stream: a deferred gate is not in it)
 	}
 	return MTR_OK;
 }

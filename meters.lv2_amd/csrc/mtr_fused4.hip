@@ -471,8 +471,9 @@ extern "C" int mtr_debug_f4_prof (unsigned long long* out)
 
 // New 47-frame history = the last 47 frames of (old history ++ this call's audio): what Resampler::process keeps in its
 // window between calls (zita-resampler/resampler.cc:229-262).
+// With a deferred gate (mtr_engine.hip) it also folds the call's true peak, in the gate's place: one lane per stream.
 __global__ void k_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
-                           float* hist_out, uint32_t n_streams)
+                           float* hist_out, uint32_t n_streams, mtr_stream_state* fold_state)
 {
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_streams * MTR_FIR_HALO) return;
@@ -482,14 +483,15 @@ __global__ void k_history (const float* audio, uint64_t stride, uint64_t n_frame
 	const v2f* hin = reinterpret_cast<const v2f*> (hist_in) + (size_t) s * MTR_FIR_HALO;
 	v2f* hout = reinterpret_cast<v2f*> (hist_out) + (size_t) s * MTR_FIR_HALO;
 	hout[i] = (f >= 0) ? src[f] : hin[MTR_FIR_HALO + f];
+	if (fold_state && i == 0) mtr_fold_truepeak (fold_state + s);
 }
 
 int mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
-                        float* hist_out, uint32_t n_streams, void* stream)
+                        float* hist_out, uint32_t n_streams, mtr_stream_state* fold_state, void* stream)
 {
 	const uint32_t n = n_streams * MTR_FIR_HALO;
 	hipLaunchKernelGGL (k_history, dim3 ((n + 255) / 256), dim3 (256), 0, (hipStream_t) stream,
-	                    audio, stride, n_frames, hist_in, hist_out, n_streams);
+	                    audio, stride, n_frames, hist_in, hist_out, n_streams, fold_state);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 

@@ -143,12 +143,15 @@ __global__ __launch_bounds__ (256) void k_gate (const mtr_gate_args a)
 	__shared__ float   sh_red[2][256];
 	__shared__ int32_t sh_cnt[4];               // cnt_M cnt_S err_M err_S
 
-	const uint32_t s = blockIdx.x;
 	const int tid = threadIdx.x;
+	// (a workgroup walks streams blockIdx.x, blockIdx.x + gridDim.x, ...: one each when the grid is the batch — the serial
+	// order — sixteen each in the deferred tail's 512-workgroup launch, see mtr_launch_gate)
+	for (uint32_t s = blockIdx.x; s < a.n_streams; s += gridDim.x) {
 	mtr_stream_state* const st = a.state + s;
 	const float* const tp = a.tile_power + (size_t) s * a.n_tiles;
 	int32_t* const ghist = a.hist + (size_t) s * 2 * MTR_HIST_LEN;
 
+	__syncthreads ();                              // (the previous stream's last readers of the shared arrays)
 	for (int i = tid; i < 64; i += 256) pw[i] = st->ring[i];
 	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) (&sh_hist[0][0])[i] = ghist[i];
 	if (tid < 4) sh_cnt[tid] = (tid == 0) ? st->cnt_M : (tid == 1) ? st->cnt_S : (tid == 2) ? st->err_M : st->err_S;
@@ -244,15 +247,13 @@ __global__ __launch_bounds__ (256) void k_gate (const mtr_gate_args a)
 		st->div1 = a.integr ? (div1_0 + (int) a.n_frag) % 2 : div1_0;
 		st->div2 = a.integr ? (div2_0 + (int) a.n_frag) % 10 : div2_0;
 		st->cnt_M = sh_cnt[0]; st->cnt_S = sh_cnt[1]; st->err_M = sh_cnt[2]; st->err_S = sh_cnt[3];
-		// true-peak hold
-		const float cl = __uint_as_float (st->tp_call[0]), cr = __uint_as_float (st->tp_call[1]);
-		st->tp_last[0] = cl; st->tp_last[1] = cr;
-		if (cl > st->tp_hold[0]) st->tp_hold[0] = cl;
-		if (cr > st->tp_hold[1]) st->tp_hold[1] = cr;
-		st->tp_call[0] = 0; st->tp_call[1] = 0;
+		// true-peak hold (a deferred gate runs beside the next call's fused kernel, which is already raising tp_call:
+		// then k_history has folded it on the caller's stream — mtr_fold_truepeak, mtr_internal.h)
+		if (a.fold_tp) mtr_fold_truepeak (st);
 	}
 	for (int i = tid; i < 64; i += 256) st->ring[i] = pw[i];
 	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) ghist[i] = (&sh_hist[0][0])[i];
+	}
 }
 
 // ---- long calls: the same bookkeeping spread over many workgroups per stream ----------------------------
@@ -402,16 +403,27 @@ __global__ __launch_bounds__ (256) void k_gate_final (const mtr_gate_args a)
 		st->div1 = a.integr ? (div1_0 + n) % 2 : div1_0;
 		st->div2 = a.integr ? (div2_0 + n) % 10 : div2_0;
 		st->cnt_M = sh_cnt[0]; st->cnt_S = sh_cnt[1]; st->err_M = sh_cnt[2]; st->err_S = sh_cnt[3];
-		const float cl = __uint_as_float (st->tp_call[0]), cr = __uint_as_float (st->tp_call[1]);
-		st->tp_last[0] = cl; st->tp_last[1] = cr;
-		if (cl > st->tp_hold[0]) st->tp_hold[0] = cl;
-		if (cr > st->tp_hold[1]) st->tp_hold[1] = cr;
-		st->tp_call[0] = 0; st->tp_call[1] = 0;
+		if (a.fold_tp) mtr_fold_truepeak (st);
 	}
 	__syncthreads ();
 	// only the bins the late inserts touched differ from the global histogram: write all back
 	for (int i = tid; i < 2 * MTR_HIST_LEN; i += 256) ghist[i] = (&sh_hist[0][0])[i];
 	if (tid < 64) st->ring[tid] = pw[128 + tid];
+}
+
+// One wave that does nothing for `us` microseconds (s_memrealtime: the 100 MHz constant clock), asleep most of the time.
+// The deferred tail starts with it: see mtr_engine.hip (tail_delay_us).
+__global__ void k_delay (uint32_t us)
+{
+	const uint64_t t0 = wall_clock64 ();
+	const uint64_t ticks = (uint64_t) us * 100u;
+	while (wall_clock64 () - t0 < ticks) __builtin_amdgcn_s_sleep (64);
+}
+
+int mtr_launch_delay (uint32_t us, void* stream)
+{
+	hipLaunchKernelGGL (k_delay, dim3 (1), dim3 (64), 0, (hipStream_t) stream, us);
+	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 
 int mtr_launch_gate (const mtr_gate_args& a, void* stream)
@@ -423,7 +435,12 @@ int mtr_launch_gate (const mtr_gate_args& a, void* stream)
 		hipLaunchKernelGGL (k_gate_final, dim3 (a.n_streams), dim3 (256), 0, (hipStream_t) stream, a);
 		return hipGetLastError () == hipSuccess ? 0 : -1;
 	}
-	hipLaunchKernelGGL (k_gate, dim3 (a.n_streams), dim3 (256), 0, (hipStream_t) stream, a);
+	// A deferred gate (a.polite_grid) runs beside the next call's fused kernel, whose one-wave workgroups own a SIMD each for
+	// the whole call: two gate workgroups per CU — two 72-VGPR waves per SIMD, 19 KB of LDS — always leave room for one of
+	// those (344 VGPRs of 512, 35 KB of 160), so the gate is launched as that many workgroups, each walking its share of the
+	// streams, and cannot stand in the way of k_seg's placement whenever the two are dispatched together.
+	const uint32_t grid = a.polite_grid ? (a.n_streams < a.polite_grid ? a.n_streams : a.polite_grid) : a.n_streams;
+	hipLaunchKernelGGL (k_gate, dim3 (grid), dim3 (256), 0, (hipStream_t) stream, a);
 	return hipGetLastError () == hipSuccess ? 0 : -1;
 }
 

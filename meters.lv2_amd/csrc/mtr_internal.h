@@ -92,6 +92,8 @@ struct mtr_gate_args {
 	float           fragm;        /* frames per fragment, as float */
 	int32_t         integr;       /* integration on? */
 	int32_t*        max_scratch;  /* [S][2] max-hold of M / S as sortable ints, for the multi-workgroup path */
+	uint32_t        polite_grid;  /* 0: one workgroup per stream; else at most this many workgroups, each walking several streams (deferred gate) */
+	int32_t         fold_tp;      /* 1: fold tp_call into tp_last / tp_hold here (the serial order); 0: k_history has done it (deferred gate) */
 };
 
 struct mtr_bank_args {
@@ -196,8 +198,9 @@ void mtr_kmeter_powers (float omega, double* pw1 /* [3] */);
 uint32_t mtr_kmeter_pieces (uint64_t n_groups);
 int  mtr_fused2_upload_taps (const float* g144);
 int  mtr_launch_history (const float* audio, uint64_t stride, uint64_t n_frames, const float* hist_in,
-                         float* hist_out, uint32_t n_streams, void* stream);
+                         float* hist_out, uint32_t n_streams, mtr_stream_state* fold_state /* NULL: k_gate folds the peaks */, void* stream);
 int  mtr_launch_gate (const mtr_gate_args& a, void* stream);
+int  mtr_launch_delay (uint32_t us, void* stream);
 int  mtr_launch_state_init (mtr_stream_state* st, int32_t* hist, uint32_t n_streams, int what, void* stream);
 int  mtr_launch_bank (const mtr_bank_args& a, void* stream);
 int  mtr_launch_tpb (const mtr_tpb_args& a, void* stream);
@@ -210,6 +213,19 @@ int  mtr_launch_history_mono (const float* audio, uint64_t stride, uint64_t n_fr
 int  mtr_launch_aggregate (const mtr_stream_state* st, const int32_t* hist, uint32_t n_streams, int32_t* d_hist, float* d_max, void* stream);
 int  mtr_launch_synth (float* d_audio, uint32_t n_streams, uint64_t n_frames, uint64_t stride,
                        uint32_t seed, float fs, int kind, void* stream);
+#endif
+
+#ifdef __HIPCC__
+/* TruePeakdsp::read () as the LV2 glue uses it (src/ebulv2.cc:361-365): the call's peak becomes the value a getter sees and
+ * enters the max-hold; tp_call is zero again for the next call's atomicMax.  One lane per stream. */
+__device__ __forceinline__ void mtr_fold_truepeak (mtr_stream_state* st)
+{
+	const float cl = __uint_as_float (st->tp_call[0]), cr = __uint_as_float (st->tp_call[1]);
+	st->tp_last[0] = cl; st->tp_last[1] = cr;
+	if (cl > st->tp_hold[0]) st->tp_hold[0] = cl;
+	if (cr > st->tp_hold[1]) st->tp_hold[1] = cr;
+	st->tp_call[0] = 0; st->tp_call[1] = 0;
+}
 #endif
 
 #define MTR_INIT_ALL     0

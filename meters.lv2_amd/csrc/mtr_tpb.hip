@@ -212,7 +212,7 @@ __global__ __launch_bounds__ (NTHREADS) void k_tpb (const mtr_tpb_args a)
 	const int srot = f16_rot (scol);
 
 	// A WHOLE chunk travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no register holds data in flight, so nothing
-	// makes the wave wait for it but the one s_waitcnt below), issued by wave 2, THREE iterations ahead of the barrier behind
+	// makes the wave wait for it but the one s_waitcnt below), issued by wave 2, AHEAD (= 5) iterations ahead of the barrier behind
 	// which the split reads it: HBM's latency is ~2500 cycles under this kernel's access pattern — one 128-byte line per stream
 	// and chunk, 1 MB in flight chip-wide per chunk of prefetch distance — more than a whole chunk's time.  (Rounds 2 and 3 loaded
 	// a chunk into registers and used it in the same iteration; round 4's first forms kept it in registers across the barrier:

@@ -43,6 +43,24 @@ def make_comm(rank, world, device=0, timeout_ms=0, before_init=None):
     return _engine.Comm(rank, world, uid[0], device, timeout_ms=timeout_ms)
 
 
+def _abandon_group(dist, group):
+    """A NCCL group whose probe timed out holds an unfinished collective: abort it (ProcessGroupNCCL.abort / _shutdown where
+    this torch has them) so that nothing at teardown waits for a peer that never answered.  Best effort, never raises."""
+    try:
+        backend = group._get_backend(__import__("torch").device("cuda"))
+    except Exception:                                             # noqa: BLE001
+        backend = None
+    for obj, name in ((backend, "abort"), (backend, "_shutdown"), (group, "abort"), (group, "_shutdown")):
+        fn = getattr(obj, name, None) if obj is not None else None
+        if callable(fn):
+            try:
+                fn()
+                return True
+            except Exception:                                     # noqa: BLE001
+                continue
+    return False
+
+
 def agree_on_collective(rank, world, make, device=None, allow_nccl=True, log=None, probe_timeout_s=60.0):
     """How the ranks of a job reduce — decided TOGETHER, so that no rank ever sits alone inside a collective.
 
@@ -115,6 +133,9 @@ def agree_on_collective(rank, world, make, device=None, allow_nccl=True, log=Non
                     ok = int(probe.item()) == world
                 else:
                     why += "; torch NCCL group: the probe all-reduce did not finish within %g s" % probe_timeout_s
+                    # the all-reduce is still outstanding on this group: it must not be waited for at teardown (destroy_process_group
+                    # would sit in it for good) — abort the group's communicators where this torch can, else shut it down
+                    _abandon_group(dist, group)
             except Exception as ex:                               # noqa: BLE001
                 why += "; torch NCCL group: %r" % (ex,)
             ok = agreed(ok)

@@ -26,6 +26,8 @@ class EngineError(RuntimeError):
     code = 0
 
 
+ABI_VERSION = 2            # MTR_ABI_VERSION of include/mtr_engine.h this file binds
+
 ERR_ARG, ERR_UNSUPPORTED, ERR_NODEVICE, ERR_HIP, ERR_NOMEM, ERR_TIMEOUT, ERR_STATE = -1, -2, -3, -4, -5, -6, -7
 
 
@@ -92,6 +94,12 @@ def _load():
     vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
     L.mtr_last_error.restype = C.c_char_p
     L.mtr_version.restype = C.c_char_p
+    # the entry points bound below are those of ABI version ABI_VERSION: an older library (MTR_LIB pointing at a stale
+    # build) is named as such here instead of failing somewhere below with an AttributeError
+    have = L.mtr_abi_version() if hasattr(L, "mtr_abi_version") else 0
+    if have < ABI_VERSION:
+        raise ImportError(f"{lib_path} speaks ABI version {have}, this binding needs {ABI_VERSION} (include/mtr_engine.h): rebuild it "
+                          "with `python -c 'import __graft_entry__ as g; g.build()'`")
     L.mtr_engine_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
     L.mtr_engine_destroy.argtypes = [vp]
     L.mtr_engine_destroy.restype = None
@@ -125,6 +133,11 @@ def _load():
     L.mtr_comm_init_timeout.argtypes = [C.POINTER(vp), i32, i32, vp, i32, u32, C.POINTER(f32)]
     L.mtr_comm_probe.argtypes = [vp, u32, C.POINTER(f32)]
     L.mtr_comm_set_timeout.argtypes = [vp, u32]
+    L.mtr_comm_nranks.argtypes = [vp]
+    L.mtr_comm_device.argtypes = [vp]
+    L.mtr_engine_set_deferred_tail.argtypes = [vp, C.c_int]
+    L.mtr_engine_join.argtypes = [vp, vp]
+    L.mtr_engine_deferred_stats.argtypes = [vp, C.POINTER(u64)]
     L.mtr_rccl_version.argtypes = []
     L.mtr_engine_state_bytes.argtypes = [vp, u32]
     L.mtr_engine_state_bytes.restype = C.c_size_t
@@ -252,6 +265,20 @@ class Comm:
     def set_timeout(self, timeout_ms):
         _check(lib.mtr_comm_set_timeout(self._h, int(timeout_ms)), "comm_set_timeout")
 
+    def nranks(self):
+        """ncclCommCount: the ranks RCCL itself sees in this communicator."""
+        n = lib.mtr_comm_nranks(self._h)
+        if n < 0:
+            _check(n, "comm_nranks")
+        return n
+
+    def device(self):
+        """ncclCommCuDevice: the device RCCL bound this rank to."""
+        d = lib.mtr_comm_device(self._h)
+        if d < 0:
+            _check(d, "comm_device")
+        return d
+
     def close(self):
         if self._h:
             lib.mtr_comm_destroy(self._h)
@@ -329,6 +356,19 @@ class Engine:
 
     def sync(self):
         _check(lib.mtr_engine_sync(self._h), "sync")
+
+    def set_deferred_tail(self, mode):
+        """0 auto / 1 never / 2 always: k_gate (and the reduction) of a call on the engine's side stream, beside the next call."""
+        _check(lib.mtr_engine_set_deferred_tail(self._h, int(mode)), "set_deferred_tail")
+
+    def join(self, stream=0):
+        """`stream` waits for what the engine's side stream holds (before reading reduce()'s buffers in stream order)."""
+        _check(lib.mtr_engine_join(self._h, stream), "join")
+
+    def deferred_calls(self):
+        n = C.c_uint64()
+        _check(lib.mtr_engine_deferred_stats(self._h, C.byref(n)), "deferred_stats")
+        return n.value
 
     def results(self, first=0, count=None):
         count = self.n_streams - first if count is None else count

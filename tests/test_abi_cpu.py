@@ -24,7 +24,11 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 28
     for n in names:
         assert hasattr(M.lib, n), f"{n} declared in include/mtr_engine.h but not exported"
-    assert M.lib.mtr_abi_version() == 1
+    assert M.lib.mtr_abi_version() == M.engine.ABI_VERSION == 2
+    hdr = open(os.path.join(os.path.dirname(HERE), "include", "mtr_engine.h")).read()
+    assert re.search(r"#define\s+MTR_ABI_VERSION\s+2\b", hdr)
+    for n in ("mtr_engine_set_deferred_tail", "mtr_engine_join", "mtr_engine_deferred_stats", "mtr_comm_nranks", "mtr_comm_device"):
+        assert n in names                                   # (round 6)
 
 
 def test_product_never_touches_the_oracle():

@@ -176,6 +176,50 @@ def test_import_refuses_what_does_not_fit(M):
         assert now == [was[1], was[2], was[2], was[3]] and len(set(was)) == 4
 
 
+def test_import_checks_the_blob_before_it_trusts_it(M):
+    """a checkpoint that rotted — a flipped bit in the payload, a fragment cursor of 0 or beyond the fragment, an
+    open DR-14 window longer than a window — is refused with MTR_ERR_STATE and leaves the engine untouched (still fresh: the
+    good blob goes in afterwards and processing continues bit for bit); and the documented asymmetry: a fresh engine on which
+    integr_start () was called takes the BLOB's integration flag."""
+    import struct
+    import torch
+    fs, T = 48000.0, 9000
+    meters = M.METER_EBU | M.METER_TRUEPEAK
+    x = np.stack([sig.g2(T, 80 + s) for s in range(3)])
+    dev = torch.from_numpy(x).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    with M.Engine(3, fs, meters) as e:
+        e.process_device(dev.data_ptr(), 3000, T, st)                      # integration OFF (never started)
+        blob = e.state_export()
+        e.process_device(dev.data_ptr() + 3000 * 8, 6000, T, st)
+        want = _records(M, e, meters)
+    # header: magic, version, header_bytes, meters, n_channels, rate, count, per_stream, stream_state_bytes, frcnt, integr, omega, dr_scnt, fnv
+    hdr = struct.Struct("<IIIIIfIIIIIfQQ")
+    f = list(hdr.unpack_from(blob))
+    assert f[1] == 2 and f[9] == 2400 - 3000 % 2400 and f[10] == 0
+
+    def with_field(i, v):
+        g = list(f); g[i] = v
+        return hdr.pack(*g) + blob[hdr.size:]
+    rotten = [bytearray(blob) for _ in range(2)]
+    rotten[0][hdr.size + 5] ^= 0x10                                        # one bit of stream 0's K-filter state
+    rotten[1][-1] ^= 0x01                                                  # the last byte of the payload
+    bad = [bytes(r) for r in rotten] + [with_field(9, 0), with_field(9, 2401), with_field(9, 1 << 31), with_field(10, 7),
+                                        with_field(11, 2.0), with_field(12, 1 << 40)]
+    with M.Engine(3, fs, meters) as o:
+        o.integr_start()                                                   # overridden by the import below: the blob says off
+        for b in bad:
+            with pytest.raises(M.EngineError) as ei:
+                o.state_import(b)
+            assert ei.value.code == M.engine.ERR_STATE
+        assert o.state_import(blob) == 3                                   # still a fresh engine: nothing above moved it
+        o.process_device(dev.data_ptr() + 3000 * 8, 6000, T, st)
+        got = _records(M, o, meters)
+    for k in want:
+        assert np.array_equal(want[k], got[k], equal_nan=True), k
+    assert want["counts"].sum() == 0                                       # integration stayed off, as in the blob
+
+
 WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist

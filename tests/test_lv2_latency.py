@@ -57,12 +57,12 @@ def test_a_host_that_states_its_block_length_gets_it_warmed_up(host):
     """options:options with buf-size:maxBlockLength = 32768: instantiate() prepares the engine for blocks of that size, so the
     first run() of 32768 frames does not pay for page-locked and device staging buffers (without the option the engine is
     warmed for 8192 frames and the first larger block allocates)."""
-    # (an allocation in the first run() is deterministic, a scheduler hiccup of the shared host is not: a fresh instance gets a
-    # second chance before the claim is judged)
-    for _ in range(3):
-        told = run_latency(host, "dBTPstereo", 32768, blocks=12, warm=0, max_block_length=32768)
-        if told["first10_max_us"] < 1.05 * told["median_us"] + 100.0:
-            break
+    # An allocation in the first run() is deterministic, a scheduler hiccup of the shared host is not.  The claim is judged
+    # against the UNTOLD instance on the same box, attempt by attempt (ADVICE r5: no retry-until-green): told must keep its first
+    # block within 5 % + 100 us of its own median in at least 2 of 3 fresh instances.
+    bound = lambda r: 1.05 * r["median_us"] + 100.0                          # noqa: E731
+    tolds = [run_latency(host, "dBTPstereo", 32768, blocks=12, warm=0, max_block_length=32768) for _ in range(3)]
     untold = run_latency(host, "dBTPstereo", 32768, blocks=12, warm=0)
-    print("dBTPstereo n=32768: first block %.0f us told / %.0f us untold, median %.0f us" % (told["first10_max_us"], untold["first10_max_us"], told["median_us"]))
-    assert told["first10_max_us"] < 1.05 * told["median_us"] + 100.0, told      # (untold: + ~0.3 ms of hipHostMalloc / hipMalloc, printed above)
+    good = [t for t in tolds if t["first10_max_us"] < bound(t)]
+    print("dBTPstereo n=32768: first block %s us told / %.0f us untold, median %.0f us" % ([round(t["first10_max_us"]) for t in tolds], untold["first10_max_us"], tolds[0]["median_us"]))
+    assert len(good) >= 2, tolds      # (untold: + ~0.3 ms of hipHostMalloc / hipMalloc, printed above)
