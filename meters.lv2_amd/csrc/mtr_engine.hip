@@ -928,7 +928,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	if (tm) { hipEvent_t v = next_event (e, ev0); if (v) HIPCHK (hipEventRecord (v, st)); }
 
 	// the tail of this call (k_gate; the job's reduction if mtr_engine_reduce follows) on the side stream?
-	const bool defer = (ebu || tp) && (e->tail_mode == 2 || (e->tail_mode == 0 && (uint64_t) S * n_frames >= TAIL_AUTO_FRAMES));
+	const bool defer = (ebu || tp) && (e->tail_mode == 2 || (e->tail_mode == 0 && e->v_cnt == 0 && (uint64_t) S * n_frames >= TAIL_AUTO_FRAMES));   // (auto: never the chunks of a host call — link-bound)
 	if (defer) { const int trc = tail_setup (e); if (trc) return trc; }
 	else if (ebu || tp) { const int jrc = join_tail (e, st); if (jrc) return jrc; }   // a serial gate follows the deferred ones
 	e->last_deferred = defer;

@@ -11,9 +11,14 @@ Tolerances (stated once, used everywhere below):
   * true-peak ballistics (TruePeakdsp::process: level m and raw peak p of every call): 4e-6 RELATIVE TO THE VALUE ITSELF
     (3.5e-5 dB), at any level — never "of max (1, value)".
   * band levels of the 30-band bank: 1e-3 dB above -90 dB.
-  * integer histograms: identical except for bin-edge flips (a fragment's loudness within ~1e-6 relative of a
-    0.1 dB edge: the time-parallel power sum differs from the serial one in the last bits): at most 2 points
-    per histogram may sit in the neighbouring bin, whatever the number of points.
+  * integer histograms ("bit-exact target"): identical except for bin-edge flips — a fragment's loudness within
+    ~1e-6 relative of a 0.1 dB edge: the kernels fuse the recurrence's multiply-adds and sum a fragment's power in another
+    order than the serial loop, so its last bits differ and such a point lands in the neighbouring bin.  That is a RATE, and
+    the bound scales with the count: at most max (2, ceil (5e-4 x points)) points of a histogram may sit
+    in a NEIGHBOURING bin (never further), counts identical — moved_allowed () below; the rate actually measured is printed
+    by the full-size tests (one stream x 3600 s: 36 000 + 7 200 points; 512 streams of the 8192 x 10 s batch: 51 200 +
+    10 240 points) and recorded in DESIGN.md 4 — and the programme record of SUMMED histograms (mtr_hist_loudness, what
+    mtr_engine_reduce feeds) must stay within 0.01 dB of the oracle's summed histograms.
 """
 import os
 import sys
@@ -34,7 +39,31 @@ G = np.load(os.path.join(HERE, "golden", "golden_v1.npz"))
 DB_TOL = 1e-3
 CONTRACT_DB = 0.01
 TPB_REL = 4e-6             # TruePeakdsp::process, level and peak of a call: relative to the value (jmeters/truepeakdsp.cc:58-84)
-MOVED_MAX = 2              # histogram points in a neighbouring 0.1 dB bin, at most, whatever the count: ONE bound for every check in this file
+MOVED_MAX = 2              # histogram points in a neighbouring 0.1 dB bin for the fixture-sized checks (<= 4300 points: the rate bound's floor)
+MOVED_RATE = 5e-4          # ... and per point for the big ones
+
+
+def moved_allowed(points):
+    return max(MOVED_MAX, int(np.ceil(MOVED_RATE * points)))
+
+
+def moved_points(got, want):
+    """(points that sit in another bin, the farthest any of them went in bins) between two histograms of equal count."""
+    got, want = np.asarray(got, np.int64), np.asarray(want, np.int64)
+    assert got.sum() == want.sum(), (got.sum(), want.sum())
+    d = got - want
+    moved = int(np.abs(d).sum() // 2)
+    # a point that moved one bin leaves +1 / -1 in adjacent bins: the running sum of d never exceeds the moved count in
+    # magnitude and returns to zero; its longest non-zero run is the farthest a point travelled
+    far = 0
+    for row in d.reshape(-1, d.shape[-1]):
+        if not row.any():
+            continue
+        c = 0
+        for x in np.cumsum(row):
+            c = c + 1 if x != 0 else 0
+            far = max(far, c)
+    return moved, far
 
 
 @pytest.fixture(scope="module")
@@ -346,6 +375,28 @@ def test_full_size_properties(M, oracle, fs):
         assert np.allclose(a[1][s], oracle.tp(host[s], fs, 8192), rtol=2e-6), s
         assert np.abs(a[2][s] - o["hist_M"]).sum() // 2 <= MOVED_MAX and np.abs(a[3][s] - o["hist_S"]).sum() // 2 <= MOVED_MAX
     assert a[2].sum() == S * 100 and a[3].sum() == S * 20    # every stream: 100 M points, 20 S points
+    # The histogram flip RATE, measured: every 16th stream of the batch against the oracle — 51 200 M points
+    # and 10 240 S points — and the programme record of the SUMMED histograms (what mtr_engine_reduce feeds mtr_hist_loudness)
+    # against the oracle's summed histograms.
+    wide = list(range(0, S, 16))
+    hw = torch.stack([buf[s] for s in wide]).cpu().numpy()
+    oh = [oracle.ebu(hw[i], fs, int(fs) // 20) for i in range(len(wide))]
+    del hw
+    om, os_ = np.stack([o["hist_M"] for o in oh]), np.stack([o["hist_S"] for o in oh])
+    mv_m, far_m = moved_points(a[2][wide], om)
+    mv_s, far_s = moved_points(a[3][wide], os_)
+    worst = max(int(np.abs(a[2][wide[i]] - om[i]).sum() // 2) for i in range(len(wide)))
+    prog_g = M.hist_loudness(a[2][wide].sum(0), a[3][wide].sum(0))
+    prog_o = M.hist_loudness(om.sum(0), os_.sum(0))
+    print("\nhistogram flips at %g Hz over %d streams: M %d of %d points (%.2e per point, farthest %d bin), S %d of %d (%.2e), worst stream %d; "
+          "programme I %.4f vs %.4f LUFS, LRA edges %s vs %s"
+          % (fs, len(wide), mv_m, om.sum(), mv_m / om.sum(), far_m, mv_s, os_.sum(), mv_s / max(os_.sum(), 1), worst,
+             prog_g[0], prog_o[0], prog_g[2:4], prog_o[2:4]))
+    assert mv_m <= moved_allowed(om.sum()) and mv_s <= moved_allowed(os_.sum()) and far_m <= 1 and far_s <= 1
+    assert abs(prog_g[0] - prog_o[0]) <= CONTRACT_DB and abs(prog_g[1] - prog_o[1]) <= CONTRACT_DB
+    assert abs(prog_g[2] - prog_o[2]) <= 0.1001 and abs(prog_g[3] - prog_o[3]) <= 0.1001 and abs(prog_g[4] - prog_o[4]) <= CONTRACT_DB
+    dev_i = max(abs(float(a[0][wide[i], 4]) - float(oh[i]["out9"][4])) for i in range(len(wide)))
+    assert dev_i <= CONTRACT_DB, dev_i
     buf.mul_(2.0)
     torch.cuda.synchronize()
     c = run(buf.data_ptr())
@@ -359,6 +410,156 @@ def test_full_size_properties(M, oracle, fs):
         e.process_device(small.data_ptr(), T)
         o9, tp = e.out9(), e.truepeak()
     assert np.allclose(o9[:, :4], c[0][pick, :4], atol=1e-4) and np.allclose(tp, c[1][pick], rtol=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_config1_one_stream_one_hour_whole_record(M, oracle):
+    """BASELINE configs[1] at its stated size: ONE stream x 3600 s at 48 kHz (172.8 M frames, 1.38 GB) in one call —
+    k_kw with thousands of time segments, the multi-workgroup gate over 72 000 fragments, 36 000 + 7 200 histogram points
+    (Ebu_r128_proc::process, ebumeter/ebu_r128_proc.cc:207-248).  The WHOLE record against the oracle: nine floats, both
+    histograms, both counts, every one of the 72 000 fragment powers; then the same hour with the true peak beside it
+    (k_kwtp16: one stream cannot fill k_seg's lanes) — same record within the same bounds, peak against oracle.tp over the
+    whole hour.  Prints the number of histogram points that sit in a neighbouring bin."""
+    import torch
+    fs, T = 48000.0, 3600 * 48000
+    buf = torch.empty((1, T, 2), dtype=torch.float32, device="cuda")
+    M.synth_fill_device(buf.data_ptr(), 1, T, T, 4242, fs, 1)
+    torch.cuda.synchronize()
+    x = buf[0].cpu().numpy()
+    o = oracle.ebu(x, fs, 4096, want_frag=True)
+    assert o["frag_power"].shape == (72000,) and tuple(o["counts"]) == (36000, 7200)
+
+    def check(e, tag):
+        got9 = e.out9()[0]
+        hm, hs = e.histograms()
+        r = e.results()[0]
+        frag = e.fragment_powers()[0]
+        assert (r.hist_M_count, r.hist_S_count) == (36000, 7200)
+        assert frag.shape == (72000,)
+        rel = np.abs(frag.astype(np.float64) - o["frag_power"]) / o["frag_power"]
+        assert rel.max() <= 2e-5, (tag, rel.max(), int(rel.argmax()))
+        assert np.allclose(got9[:4], o["out9"][:4], atol=DB_TOL), (tag, got9, o["out9"])
+        mv_m, far_m = moved_points(hm[0], o["hist_M"])
+        mv_s, far_s = moved_points(hs[0], o["hist_S"])
+        print("\n%s, 1 stream x 3600 s: %d of 36000 M points and %d of 7200 S points in a neighbouring bin (farthest %d); largest "
+              "fragment-power deviation %.2e; I %.4f vs %.4f, LRA %.1f..%.1f vs %.1f..%.1f"
+              % (tag, mv_m, mv_s, max(far_m, far_s), rel.max(), got9[4], o["out9"][4], got9[6], got9[7], o["out9"][6], o["out9"][7]))
+        assert mv_m <= moved_allowed(36000) and mv_s <= moved_allowed(7200) and far_m <= 1 and far_s <= 1
+        assert abs(got9[4] - o["out9"][4]) <= CONTRACT_DB and abs(got9[5] - o["out9"][5]) <= CONTRACT_DB
+        assert abs(got9[6] - o["out9"][6]) <= 0.1001 and abs(got9[7] - o["out9"][7]) <= 0.1001 and abs(got9[8] - o["out9"][8]) <= CONTRACT_DB
+        if mv_m == 0 and mv_s == 0:
+            # identical histograms -> the identical gated record: the LRA edges (bin indices) bit for bit; I and the two
+            # thresholds to the last ulp or two — they are 10 log10f (s) of identical sums, and the device's log10f is the
+            # correctly rounded one ((float) log10 ((double) s)) while this image's glibc 2.35 log10f is only within ~2 ulp of
+            # it (measured here: range_thr -31.482706 vs -31.482708): 4e-7 relative = 1e-5 dB
+            assert got9[6] == o["out9"][6] and got9[7] == o["out9"][7]
+            assert np.allclose(got9[[4, 5, 8]], o["out9"][[4, 5, 8]], rtol=4e-7, atol=0)
+        return got9, hm, hs, frag
+
+    with M.Engine(1, fs, M.METER_EBU) as e:
+        e.integr_start()
+        e.process_device(buf.data_ptr(), T)
+        assert e.layout() == 4
+        first = check(e, "EBU R128 (k_kw)")
+        e.reset(); e.integr_start()
+        e.process_device(buf.data_ptr(), T)                                # deterministic
+        again = (e.out9()[0], *e.histograms(), e.fragment_powers()[0])
+        for u, v in zip(first, again):
+            assert np.array_equal(u, v)
+    with M.Engine(1, fs, M.METER_EBU | M.METER_TRUEPEAK) as e:
+        e.integr_start()
+        e.process_device(buf.data_ptr(), T)
+        check(e, "EBU R128 + true peak (k_kwtp16)")
+        assert np.allclose(e.truepeak()[0], oracle.tp(x, fs, 8192), rtol=2e-6)
+
+
+@pytest.mark.timeout(900)
+def test_config2_truepeak_alone_full_size(M, oracle):
+    """BASELINE configs[2] at its stated size: 4x true peak alone, 1024 streams x 60 s (23.6 GB) — TruePeakdsp::process_max
+    (jmeters/truepeakdsp.cc:101-124) over Resampler::process: deterministic, peaks double exactly under a power-of-two gain,
+    the same audio at another batch index gives the same peaks, 34 sampled streams against oracle.tp over their whole minute."""
+    import torch
+    fs, S, T = 48000.0, 1024, 60 * 48000
+    free, _ = torch.cuda.mem_get_info()
+    if free < (S * T * 8) * 1.05:
+        S = int(free * 0.9 / (T * 8)) // 64 * 64
+    buf = torch.empty((S, T, 2), dtype=torch.float32, device="cuda")
+    M.synth_fill_device(buf.data_ptr(), S, T, T, 2024, fs, 1)
+    torch.cuda.synchronize()
+    pick = sorted({0, 1, S // 2 + 3, S - 1} | {(S * k) // 31 + (7 * k) % 13 for k in range(1, 31)})
+
+    def run(ptr, n=S):
+        with M.Engine(n, fs, M.METER_TRUEPEAK) as e:
+            e.process_device(ptr, T)
+            r = e.results()
+            return e.truepeak(), np.array([[x.truepeak_call[0], x.truepeak_call[1]] for x in r], np.float32), e.seg_stats()[0]
+
+    a = run(buf.data_ptr())
+    b = run(buf.data_ptr())
+    assert a[2] == 1                                          # the batch went through k_seg
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], a[1])
+    for s in pick:
+        assert np.allclose(a[0][s], oracle.tp(buf[s].cpu().numpy(), fs, 8192), rtol=2e-6), s
+    small = torch.stack([buf[s] for s in pick])
+    c = run(small.data_ptr(), len(pick))
+    assert np.allclose(c[0], a[0][pick], rtol=1e-6)           # (34 streams plan other segments than 1024: same peaks to the last bits of the f16 split)
+    buf.mul_(2.0)
+    torch.cuda.synchronize()
+    d = run(buf.data_ptr())
+    assert np.array_equal(d[0], 2 * a[0])                    # peaks double exactly
+    assert (a[0] > 0.05).all() and (a[0] < 2.0).all()
+
+
+@pytest.mark.timeout(1200)
+def test_config4_three_meters_in_one_engine_full_size(M):
+    """BASELINE configs[4]'s per-GPU shard with everything on: EBU R128 + true peak + the 30-band bank in ONE engine at
+    8192 streams x 10 s (spectrum_run's loop beside process / process_max: src/spectrumlv2.c:210-227, ebu_r128_proc.cc:207-248,
+    truepeakdsp.cc:101-124) must give, bit for bit, the records of the meters in separate engines over the same buffer:
+    EBU + true peak (one fused kernel either way), the bank alone, true peak alone (the same interpolator with the
+    K-filter compiled out).  EBU alone runs another kernel (k_kw: the exact time-parallel scan): its record agrees within
+    the stated tolerances, not bitwise."""
+    import torch
+    fs, S, T = 48000.0, 8192, 480000
+    free, _ = torch.cuda.mem_get_info()
+    if free < (S * T * 8) * 1.05:
+        S = int(free * 0.9 / (T * 8)) // 256 * 256
+    buf = torch.empty((S, T, 2), dtype=torch.float32, device="cuda")
+    M.synth_fill_device(buf.data_ptr(), S, T, T, 99, fs, 1)
+    torch.cuda.synchronize()
+
+    def run(meters):
+        with M.Engine(S, fs, meters) as e:
+            if meters & M.METER_EBU:
+                e.integr_start()
+            e.process_device(buf.data_ptr(), T)
+            out = {}
+            if meters & M.METER_EBU:
+                out["o9"] = e.out9()
+                out["hm"], out["hs"] = e.histograms()
+                out["frag"] = e.fragment_powers()
+            if meters & M.METER_TRUEPEAK:
+                out["tp"] = e.truepeak()
+            if meters & M.METER_SPECTR30:
+                sp = e.spectrum()
+                out["val"], out["max"] = sp["val"], sp["max"]
+            return out
+
+    all3 = run(M.METER_EBU | M.METER_TRUEPEAK | M.METER_SPECTR30)
+    two = run(M.METER_EBU | M.METER_TRUEPEAK)
+    for k in ("o9", "hm", "hs", "frag", "tp"):
+        assert np.array_equal(all3[k], two[k], equal_nan=True), k
+    bank = run(M.METER_SPECTR30)
+    for k in ("val", "max"):
+        assert np.array_equal(all3[k], bank[k]), k
+    tp = run(M.METER_TRUEPEAK)
+    assert np.array_equal(all3["tp"], tp["tp"])
+    ebu = run(M.METER_EBU)
+    assert np.allclose(ebu["o9"][:, :4], all3["o9"][:, :4], atol=DB_TOL)
+    assert np.abs(ebu["o9"][:, 4] - all3["o9"][:, 4]).max() <= CONTRACT_DB
+    assert np.allclose(ebu["frag"], all3["frag"], rtol=2e-5)
+    mv, far = moved_points(ebu["hm"], all3["hm"])
+    assert mv <= moved_allowed(S * 100) and far <= 1
+    assert all3["hm"].sum() == S * 100 and all3["hs"].sum() == S * 20 and (all3["val"] > 0).all() and (all3["tp"] > 0.05).all()
 
 
 @pytest.mark.parametrize("meters", ["ebu", "ebu+tp"])
