@@ -62,23 +62,29 @@ static void ppm_process (Ppm* p, const float* a, const float* b, int n, int mode
 }
 static float ppm_read (Ppm* p) { p->res = 1; return p->g * p->m; }
 
-/* ---- stereo correlation, stcorrdsp.cc:47-93 ---- */
+/* ---- stereo correlation (Stcorrdsp, jmeters/stcorrdsp.cc:47-93): each channel through a one-pole low-pass of 2 kHz, then the
+ * product and the two squares each through a one-pole of 0.3 s; read () divides the first by the geometric mean of the
+ * others.  Five leaky integrators z <- z + w (target - z); the two in front carry the anti-denormal bias. ---- */
 typedef struct { float zl, zr, zlr, zll, zrr, w1, w2; } Cor;
+static inline float leak_to (float z, float w, float target) { return z + w * (target - z); }
+static inline float leak_biased (float z, float w, float target) { return z + (w * (target - z) + 1e-20f); }
+static inline float finite_or_zero (float v) { return isfinite (v) ? v : 0.f; }
 static void cor_process (Cor* c, const float* pl, const float* pr, int n)
 {
-	float zl = c->zl, zr = c->zr, zlr = c->zlr, zll = c->zll, zrr = c->zrr;
-	while (n--) {
-		zl += c->w1 * (*pl++ - zl) + 1e-20f;
-		zr += c->w1 * (*pr++ - zr) + 1e-20f;
-		zlr += c->w2 * (zl * zr - zlr);
-		zll += c->w2 * (zl * zl - zll);
-		zrr += c->w2 * (zr * zr - zrr);
+	const float w_in = c->w1, w_out = c->w2;
+	float l = c->zl, r = c->zr, lr = c->zlr, ll = c->zll, rr = c->zrr;
+	for (int i = 0; i < n; ++i) {
+		l = leak_biased (l, w_in, pl[i]);
+		r = leak_biased (r, w_in, pr[i]);
+		lr = leak_to (lr, w_out, l * r);
+		ll = leak_to (ll, w_out, l * l);
+		rr = leak_to (rr, w_out, r * r);
 	}
-	c->zl = isfinite (zl) ? zl : 0;
-	c->zr = isfinite (zr) ? zr : 0;
-	c->zlr = (isfinite (zlr) ? zlr : 0) + 1e-10f;
-	c->zll = (isfinite (zll) ? zll : 0) + 1e-10f;
-	c->zrr = (isfinite (zrr) ? zrr : 0) + 1e-10f;
+	c->zl = finite_or_zero (l);
+	c->zr = finite_or_zero (r);
+	c->zlr = finite_or_zero (lr) + 1e-10f;                     /* (the denominator of read () never vanishes) */
+	c->zll = finite_or_zero (ll) + 1e-10f;
+	c->zrr = finite_or_zero (rr) + 1e-10f;
 }
 
 /* ---- K-meter: lv2_dsp.h (shared with the DR14 / TP+RMS plugins) ---- */

@@ -147,54 +147,70 @@ void mtr_setup_band (double rate, uint32_t band, double* out)
 	W[0][3] *= g; W[0][4] *= g; W[0][5] *= g;
 }
 
-/* Programme loudness / range from (possibly summed) histograms: Ebu_r128_hist::integrate,
- * calc_integ, calc_range (ebumeter/ebu_r128_proc.cc:82-150) on plain int32[751] arrays. */
-static float hl_integrate (const int32_t* h, const float* bp, int i)
+/* Programme loudness / range from (possibly summed) histograms — what Ebu_r128_hist::integrate, calc_integ and calc_range
+ * (ebumeter/ebu_r128_proc.cc:82-150) give for the same counts, on plain int32[751] arrays.  Bin b stands for the loudness
+ * (b - 700) / 10 dB; its power weight is 10^((b % 100) / 100) scaled by ten per hundred bins below the top. */
+
+/* Mean power of the points in bins [first, 750].  The float sum runs over the bins in ascending order and is divided by ten
+ * at the end of every hundred — the rounding sequence the reference's table walk has, so the result is its float. */
+static float gated_mean_power (const int32_t* h, const float* weight100, int first)
 {
-	int   j = i % 100, n = 0;
-	float s = 0;
-	while (i <= 750) {
-		const int k = h[i++];
-		n += k;
-		s += k * bp[j++];
-		if (j == 100) { j = 0; s /= 10.0f; }
+	int   points = 0;
+	float acc = 0.f;
+	for (int base = first - first % 100; base <= 750; base += 100) {
+		const int from = base < first ? first : base;
+		const int to = base + 99 < 750 ? base + 99 : 750;
+		for (int b = from; b <= to; ++b) {
+			points += h[b];
+			acc += h[b] * weight100[b - base];
+		}
+		if (to == base + 99) acc /= 10.0f;
 	}
-	return s / n;
+	return acc / points;
+}
+
+static long points_in (const int32_t* h, int from)
+{
+	long n = 0;
+	for (int b = from; b <= 750; ++b) n += h[b];
+	return n;
+}
+
+/* First bin of the relative gate: `db_below` under the ungated mean, in hundredths of a decade of power.  The rounding
+ * constant is a float for the integrated loudness and a double for the range (:121 writes 0.5f, :141 writes 0.5). */
+static int gate_bin (float mean_power, int offset, int half_is_double)
+{
+	const float c = 100 * log10f (mean_power);
+	const int k = (int) floorf (half_is_double ? c + 0.5 : c + 0.5f) + offset;
+	return k < 0 ? 0 : k;
 }
 
 void mtr_setup_hist_loudness (const int32_t* hm, const int32_t* hs, float* integ, float* integ_thr,
                               float* rmin, float* rmax, float* rthr)
 {
-	float bp[100];
-	mtr_setup_bin_power (bp);
+	float w[100];
+	mtr_setup_bin_power (w);
 	*integ = *integ_thr = *rmin = *rmax = *rthr = -200.0f;
-	if (hm) {
-		long cnt = 0;
-		for (int i = 0; i <= 750; ++i) cnt += hm[i];
-		if (cnt >= 50) {
-			float s = hl_integrate (hm, bp, 0);
-			*integ_thr = 10 * log10f (s) - 10.0f;
-			int k = (int) (floorf (100 * log10f (s) + 0.5f)) + 600;
-			if (k < 0) k = 0;
-			s = hl_integrate (hm, bp, k);
-			*integ = 10 * log10f (s);
-		}
+	if (hm && points_in (hm, 0) >= 50) {                         /* integrated loudness: the mean above (ungated mean - 10 dB) */
+		const float all = gated_mean_power (hm, w, 0);
+		*integ_thr = 10 * log10f (all) - 10.0f;
+		*integ = 10 * log10f (gated_mean_power (hm, w, gate_bin (all, 600, 0)));
 	}
-	if (hs) {
-		long cnt = 0;
-		for (int i = 0; i <= 750; ++i) cnt += hs[i];
-		if (cnt >= 20) {
-			float s = hl_integrate (hs, bp, 0);
-			*rthr = 10 * log10f (s) - 20.0f;
-			int k = (int) (floorf (100 * log10f (s) + 0.5)) + 500;
-			if (k < 0) k = 0;
-			int i, j, n = 0;
-			for (i = k; i <= 750; i++) n += hs[i];
-			const float a = 0.10f * n, b = 0.95f * n;
-			for (i = k, s = 0; s < a; i++) s += hs[i];
-			for (j = 750, s = n; s > b; j--) s -= hs[j];
-			*rmin = (i - 701) / 10.0f;
-			*rmax = (j - 699) / 10.0f;
-		}
+	if (hs && points_in (hs, 0) >= 20) {                         /* loudness range: 10th .. 95th percentile above (mean - 20 dB) */
+		const float all = gated_mean_power (hs, w, 0);
+		*rthr = 10 * log10f (all) - 20.0f;
+		const int gate = gate_bin (all, 500, 1);
+		const int n = (int) points_in (hs, gate);
+		const float low = 0.10f * n, high = 0.95f * n;
+		/* counts are integers and a float holds them exactly up to 2^24 points, so whole-number running counts compared as
+		 * floats decide every bin as the reference's float accumulators do */
+		long below = 0;                                            /* points in bins [gate, lo) */
+		int  lo = gate;
+		while ((float) below < low) below += hs[lo++];
+		long kept = n;                                             /* points in bins [gate, hi] */
+		int  hi = 750;
+		while ((float) kept > high) kept -= hs[hi--];
+		*rmin = (lo - 701) / 10.0f;
+		*rmax = (hi - 699) / 10.0f;
 	}
 }

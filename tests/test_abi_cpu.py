@@ -60,9 +60,14 @@ def test_setup_math_matches_reference_golden():
 def test_hist_loudness_matches_oracle(oracle):
     from _oracle import MoHist
     rng = np.random.default_rng(5)
-    for trial in range(20):
-        centre = rng.integers(300, 700)
-        pts = np.clip(rng.normal(centre, 40, size=rng.integers(10, 400)).astype(int), 0, 750)
+    for trial in range(400):
+        # (round 6: mtr_setup_hist_loudness is the repo's own formulation of the gated mean and the percentile walk — held bit for
+        # bit against the pinned oracle over narrow and wide programmes, a few points and summed histograms of a million, gates
+        # that fall below bin 0 and above the loudest point, counts either side of the 50 / 20 point minima)
+        centre = rng.integers(40, 745)
+        width = [3, 40, 150][trial % 3]
+        size = [rng.integers(10, 400), rng.integers(15, 60), rng.integers(100000, 1000000)][(trial // 3) % 3]
+        pts = np.clip(rng.normal(centre, width, size=size).astype(int), 0, 750)
         hm = np.bincount(pts, minlength=751).astype(np.int32)
         hs = np.bincount(np.clip(pts + rng.integers(-30, 30, pts.size), 0, 750), minlength=751).astype(np.int32)
         got = M.hist_loudness(hm, hs)

@@ -62,7 +62,7 @@ def plugin(uri, name, comment, ports, extra=""):
 
 
 def spectr(stereo):
-    p = [ctl(i, "band%d" % b, "%d Hz" % b, "Output", -100.0, 6.0) for i, b in enumerate(BANDS)]
+    p = [ctl(i, "band%d" % b, "%d Hz" % b, "Output", -100.0, 6.0, -100.0 if (i == 0 and not stereo) else None) for i, b in enumerate(BANDS)]   # (the mono plugin's band25 alone states a default)
     p += [ctl(30 + i, "max%d" % b, "%d Hz peak" % b, "Output", -100.0, 6.0) for i, b in enumerate(BANDS)]
     p += [ctl(60, "UIspeed", "Integration speed", "Input", 0.02, 15.0, 1.0),
           ctl(61, "UIreset", "Peak hold reset", "Input", -4.0, 4.0, -4.0),
@@ -82,86 +82,104 @@ NEEDLE_NAMES = {"BBC": "BBC PPM", "EBU": "EBU PPM", "DIN": "DIN PPM", "NOR": "No
                 "K12": "K12/RMS Meter", "K14": "K14/RMS Meter", "K20": "K20/RMS Meter"}
 
 
+REF_LEVEL = {"BBC": -18.0, "EBU": -18.0, "DIN": -15.0, "NOR": -18.0}     # default of port 0 per scale (lv2ttl/meters.lv2.ttl.in:112-546)
+
+
 def needles():
-    """The needle meters share VU's port map (lv2ttl/meters.lv2.ttl.in: port indices of src/meters.cc:59-70);
-    the K-meters add peak and hold outputs (mono: on the otherwise unused indices 4 and 5)."""
+    """The needle meters share VU's port map (lv2ttl/meters.lv2.ttl.in:112-602; port indices of src/meters.cc:59-70): the
+    reference level, audio through, the level in [0, 1]; the K-meters (:1976-2400) use port 0 as the peak-hold reset
+    handshake (-4 .. 4) and add peak and hold outputs (mono: on the otherwise unused indices 4 and 5)."""
     t = ""
     for n in NEEDLES:
         if n == "COR":
-            ports = [ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, -18.0), audio(1, "inL", "InL", "Input"),
-                     audio(2, "outL", "OutL", "Output"), ctl(3, "level", "Correlation", "Output", -1.0, 1.0),
+            ports = [ctl(0, "unused", "unused", "Input", 0.0, 1.0, 0.0), audio(1, "inL", "InL", "Input"),
+                     audio(2, "outL", "OutL", "Output"), ctl(3, "correlation", "Correlation", "Output", -1.0, 1.0),
                      audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output")]
             t += plugin(n, "Stereo Phase-Correlation Meter (MI355X build)", "Stereo phase correlation; host CPU.", ports)
             continue
         if n == "BBCM6":
             ports = [ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, -18.0), audio(1, "inL", "InL", "Input"),
-                     audio(2, "outL", "OutL", "Output"), ctl(3, "levelM", "Level M", "Output", 0.0, 1.0),
+                     audio(2, "outL", "OutL", "Output"), ctl(3, "levelM6", "Level M", "Output", 0.0, 1.0),
                      audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output"),
-                     ctl(6, "levelS", "Level S", "Output", 0.0, 1.0), ctl(7, "gainS", "S +20 dB", "Input", 0, 1, 0)]
+                     ctl(6, "levelS6", "Level S", "Output", 0.0, 1.0), ctl(7, "s20", "S +20 dB", "Input", 0, 1, 0)]
             t += plugin(n, "BBC M-6 PPM (MI355X build)", "Mid / side peak programme meter; host CPU.", ports)
             continue
         kind, stereo = n[:3], n.endswith("stereo")
         label = "%s (%s, MI355X build)" % (NEEDLE_NAMES[kind], "Stereo" if stereo else "Mono")
-        ports = [ctl(0, "ref", "Reference level", "Input", -30.0, 3.0, -18.0)]
+        k = kind[0] == "K"
+        ports = [ctl(0, "ref", "Peak hold reset" if k else "Reference level", "Input", -4.0, 4.0, -4.0) if k
+                 else ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, REF_LEVEL[kind])]
         if not stereo:
-            ports += [audio(1, "in", "In", "Input"), audio(2, "out", "Out", "Output"), ctl(3, "level", "Level", "Output", 0.0, 2.0)]
-            if kind[0] == "K":
-                ports += [ctl(4, "peak", "Peak", "Output", 0.0, 2.0), ctl(5, "hold", "Peak hold", "Output", -70000.0, 2.0)]
+            ports += [audio(1, "in", "In", "Input"), audio(2, "out", "Out", "Output"), ctl(3, "level1", "Level", "Output", 0.0, 1.0)]
+            if k:
+                ports += [ctl(4, "peak", "Peak", "Output", 0.0, 1.0), ctl(5, "hold", "Peak hold", "Output", 0.0, 1.0)]
         else:
-            ports += [audio(1, "inL", "InL", "Input"), audio(2, "outL", "OutL", "Output"), ctl(3, "levelL", "Level L", "Output", 0.0, 2.0),
-                      audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output"), ctl(6, "levelR", "Level R", "Output", 0.0, 2.0)]
-            if kind[0] == "K":
-                ports += [ctl(7, "peakL", "Peak L", "Output", 0.0, 2.0), ctl(8, "peakR", "Peak R", "Output", 0.0, 2.0),
-                          ctl(9, "hold", "Peak hold", "Output", -70000.0, 2.0)]
+            ports += [audio(1, "inL", "InL", "Input"), audio(2, "outL", "OutL", "Output"), ctl(3, "levelL", "Level L", "Output", 0.0, 1.0),
+                      audio(4, "inR", "InR", "Input"), audio(5, "outR", "OutR", "Output"), ctl(6, "levelR", "Level R", "Output", 0.0, 1.0)]
+            if k:
+                ports += [ctl(7, "peakL", "Peak L", "Output", 0.0, 1.0), ctl(8, "peakR", "Peak R", "Output", 0.0, 1.0),
+                          ctl(9, "hold", "Peak hold", "Output", 0.0, 1.0)]
         t += plugin(n, label, "Needle meter ballistics on the host CPU.", ports)
     return t
 
 
 DR14S = ["dr14mono", "dr14stereo", "TPnRMSmono", "TPnRMSstereo"]
-SURS = ["surround%d" % n for n in (8, 7, 6, 5, 4, 3)]
+# the reference ships metadata for 8, 5, 4 and 3 channels (lv2ttl/manifest.lv2.ttl.in:163-181; src/surmeter.c also answers
+# surround7 / surround6, which no bundle declares) — and these default channel pairs for the four correlation meters
+SURS = {"surround8": [(0, 1), (2, 3), (4, 5), (6, 7)], "surround5": [(1, 4), (2, 3), (0, 4), (0, 1)],
+        "surround4": [(0, 2), (1, 3), (0, 3), (0, 1)], "surround3": [(0, 1), (0, 2), (1, 2), (0, 0)]}
 
 
 def surrounds():
-    """src/surmeter.c:74-113: port 0 reference level, 1..12 = four x (channel a, channel b, correlation out),
-    then per channel in, out, level, peak."""
+    """src/surmeter.c:74-113, lv2ttl/meters.lv2.ttl.in (surround8 ff.): port 0 the RMS gain, 1..12 = four x (channel A,
+    channel B, correlation out), then per channel in, out, rms, peak — everything counted from 1 in the symbols."""
     t = ""
-    for n in SURS:
+    for n, pairs in SURS.items():
         chn = int(n[-1])
-        ports = [ctl(0, "ref", "Reference level", "Input", -30.0, 0.0, -18.0)]
-        for c in range(4):
-            ports += [ctl(1 + 3 * c, "cor%da" % c, "Correlation %d channel A" % c, "Input", 0, chn - 1, min(2 * c, chn - 1)),
-                      ctl(2 + 3 * c, "cor%db" % c, "Correlation %d channel B" % c, "Input", 0, chn - 1, min(2 * c + 1, chn - 1)),
-                      ctl(3 + 3 * c, "cor%d" % c, "Correlation %d" % c, "Output", -1.0, 1.0)]
+        ports = [ctl(0, "rmsgain", "RMS gain", "Input", -20.0, 20.0, 0.0)]
+        for c, (pa, pb) in enumerate(pairs):
+            ports += [ctl(1 + 3 * c, "cor%dA" % (c + 1), "Correlation %d channel A" % (c + 1), "Input", 0, chn - 1, pa),
+                      ctl(2 + 3 * c, "cor%dB" % (c + 1), "Correlation %d channel B" % (c + 1), "Input", 0, chn - 1, pb),
+                      ctl(3 + 3 * c, "cor%d" % (c + 1), "Correlation %d" % (c + 1), "Output", -1.0, 1.0)]
         for c in range(chn):
             b = 13 + 4 * c
-            ports += [audio(b, "in%d" % c, "In %d" % c, "Input"), audio(b + 1, "out%d" % c, "Out %d" % c, "Output"),
-                      ctl(b + 2, "level%d" % c, "Level %d" % c, "Output", 0.0, 2.0),
-                      ctl(b + 3, "peak%d" % c, "Peak %d" % c, "Output", 0.0, 2.0)]
+            ports += [audio(b, "in%d" % (c + 1), "In %d" % (c + 1), "Input"), audio(b + 1, "out%d" % (c + 1), "Out %d" % (c + 1), "Output"),
+                      ctl(b + 2, "rms%d" % (c + 1), "RMS %d" % (c + 1), "Output", 0.0, 1.0),
+                      ctl(b + 3, "peak%d" % (c + 1), "Peak %d" % (c + 1), "Output", 0.0, 1.0)]
         t += plugin(n, "Surround Meter (%d channels, MI355X build)" % chn, "K-meter per channel and pairwise correlation; host CPU.", ports)
     return t
 
 
 def dr14s():
-    """src/dr14.c:27-43: control atom port, three control ports, then per channel audio in / out and five bar values;
-    stereo adds the averaged DR value."""
+    """src/dr14.c:27-43, lv2ttl/meters.lv2.ttl.in (dr14mono ff.): control atom port, three control ports, then per channel audio in /
+    out and the bar values.  dr14*: five per channel (true peak, its maximum, RMS, the score, DR), stereo adds the averaged DR;
+    TPnRMS*: four per channel — the stereo variant keeps index 10 (the first channel's DR slot) as an unused output so that the
+    second channel starts at 11 as in dr14stereo, and neither declares a DR port."""
     t = ""
     for n in DR14S:
-        stereo = n.endswith("stereo")
+        stereo, dr = n.endswith("stereo"), n.startswith("dr14")
         ports = [atom_port(0, "control", "UI to plugin communication", "Input", "\t\tatom:supports time:Position ;\n"),
-                 ctl(1, "follow_transport", "Reset when the transport starts", "Input", 0, 1, 1),
+                 ctl(1, "host_transport" if dr else "unused1", "Reset when the transport starts" if dr else "unused", "Input", 0, 1, 1),
                  ctl(2, "reset", "Reset", "Input", 0, 1, 0),
-                 ctl(3, "blkcnt", "Integration time [s]", "Output", -70000.0, 360000.0)]
-        for c, suf in enumerate(("L", "R") if stereo else ("",)):
+                 ctl(3, "blkcnt", "Integration time [s]", "Output", 0.0, 3600.0 if (dr or stereo) else 1.0)]
+        for c in range(2 if stereo else 1):
             b = 4 + 7 * c
-            ports += [audio(b, "in" + suf, "In" + suf, "Input"), audio(b + 1, "out" + suf, "Out" + suf, "Output"),
-                      ctl(b + 2, "peak" + suf, "True peak " + suf, "Output", -80.0, 6.0),
-                      ctl(b + 3, "peak_max" + suf, "True peak max " + suf, "Output", -100.0, 6.0),
-                      ctl(b + 4, "rms" + suf, "RMS " + suf, "Output", -80.0, 6.0),
-                      ctl(b + 5, "rms_max" + suf, "RMS max " + suf, "Output", -100.0, 6.0),
-                      ctl(b + 6, "dr" + suf, "DR " + suf, "Output", 1.0, 21.0)]
-        if stereo:
-            ports.append(ctl(18, "dr_total", "DR", "Output", 1.0, 21.0))
-        label = ("DR-14 Crest-Factor Meter" if n.startswith("dr14") else "True-Peak and RMS Meter") + \
+            suf = str(c + 1) if stereo else ""
+            ports += [audio(b, "in%d" % (c + 1), "In %d" % (c + 1), "Input"), audio(b + 1, "out%d" % (c + 1), "Out %d" % (c + 1), "Output"),
+                      ctl(b + 2, "dBTP_m" + suf, "True peak " + suf, "Output", -80.0, 6.0),
+                      ctl(b + 3, "dBTP_p" + suf, "True peak max " + suf, "Output", -80.0, 6.0),
+                      ctl(b + 4, "dBRMS_m" + suf, "RMS " + suf, "Output", -80.0, 0.0)]
+            if dr:
+                ports += [ctl(b + 5, "dBRMS_p" + suf, "RMS score " + suf, "Output", -80.0, 0.0),
+                          ctl(b + 6, "dr" + suf, "DR " + suf, "Output", 0.0, 20.0)]
+            else:
+                # (the reference names the held K-meter peak dBRMS_p1 on the first stereo channel and dBFS_p elsewhere)
+                ports += [ctl(b + 5, "dBRMS_p1" if (stereo and c == 0) else "dBFS_p" + (suf if stereo else ""), "Peak hold " + suf, "Output", -80.0, 0.0)]
+                if stereo and c == 0:
+                    ports += [ctl(b + 6, "unused2", "unused", "Output", 0.0, 1.0)]
+        if stereo and dr:
+            ports.append(ctl(18, "dr", "DR", "Output", 0.0, 20.0))
+        label = ("DR-14 Crest-Factor Meter" if dr else "True-Peak and RMS Meter") + \
             (" (Stereo, MI355X build)" if stereo else " (Mono, MI355X build)")
         t += plugin(n, label, "True-peak ballistics, K-meter detector and the 3 s window statistics on the GPU.", ports,
                     extra="\tlv2:requiredFeature urid:map ;\n")
@@ -171,7 +189,7 @@ def dr14s():
 def main(out):
     os.makedirs(out, exist_ok=True)
     plugs = ["VUmono", "VUstereo", "EBUr128", "spectr30mono", "dBTPmono", "dBTPstereo", "spectr30stereo",
-             "SigDistHist", "bitmeter"] + NEEDLES + DR14S + SURS
+             "SigDistHist", "bitmeter"] + NEEDLES + DR14S + list(SURS)
     man = PREFIX + "".join("mtr:%s\n\ta lv2:Plugin ;\n\tlv2:binary <meters_amd.so> ;\n\trdfs:seeAlso <meters_amd.ttl> .\n\n" % p
                            for p in plugs)
     open(os.path.join(out, "manifest.ttl"), "w").write(man)
