@@ -123,6 +123,45 @@ def cpu_baseline(host_audio, fs, budget_s=9.0):
     return out
 
 
+def tpb_binding(S, T, k_ms, channels):
+    """What bounds k_tpb (TruePeakdsp::process for a batch, mtr_tpb.hip), as a number one can divide by: a workgroup = one CU walks
+    64 (stream, channel) columns in chunks of 16 frames, and a chunk costs every SIMD its share of what the twelve waves issue.
+    Per chunk and CU (profiles/r06_tpb.md: instruction counts from SQ_INSTS_*, busy cycles from SQ_ACTIVE_INST_VALU x 4,
+    SQ_VALU_MFMA_BUSY_CYCLES and SQ_LDS_IDX_ACTIVE, all / 7.68 M chunks): 725 VALU instructions = 2973 issue cycles, 72 MFMAs
+    (16x16x32 f16: 4 blocks x 18) = 1152 cycles of the matrix pipe, 168 LDS instructions = 680 cycles of the LDS.  VALU issue and
+    the matrix pipe do not overlap across the three waves of a SIMD (measured: their busy cycles ADD to 82 - 85 % of the kernel's), so the
+    floor is their sum spread evenly over the four SIMDs — 1031 cycles per chunk — at the clock the profile ran at (2.05 GHz:
+    GRBM_GUI_ACTIVE).  The chain waves alone (16 frames x 4 dependent steps of ~8 cycles + the maps' LDS round trip) need ~1040."""
+    cols = S * channels
+    chunks_per_cu = (cols + 63) // 64 * ((T + 15) // 16) / 256.0
+    floor = 2973 / 4.0 + 1152 / 4.0
+    clock_mhz = 2050.0
+    return {"bound": "SIMD issue per 16-frame chunk: VALU (725 instructions per chunk and CU) + the matrix pipe (72 MFMAs), which do not overlap across the "
+                     "waves of a SIMD; one barrier per chunk; the LDS is busy 680 cycles per chunk beside it",
+            "valu_issue_cycles_per_chunk_and_simd": 2973 / 4.0, "mfma_pipe_cycles_per_chunk_and_simd": 1152 / 4.0,
+            "lds_busy_cycles_per_chunk_and_cu": 680.0, "issue_floor_cycles_per_chunk_and_simd": floor,
+            "chain_wave_alone_cycles_per_chunk": 1040.0, "profiled_cycles_per_chunk": 1220.0,
+            "chunks_per_cu": chunks_per_cu, "kernel_ms_at_floor_and_profiled_clock_2p05_ghz": chunks_per_cu * floor / (clock_mhz * 1e3),
+            "kernel_ms_at_floor_and_2p4_ghz": chunks_per_cu * floor / 2.4e6,
+            "frac_of_floor_at_profiled_clock": chunks_per_cu * floor / (clock_mhz * 1e3) / k_ms,
+            "mfma_achieved_tflops": 2.0 * 16 * 16 * 32 * 72 * chunks_per_cu * 256 / (k_ms * 1e-3) / 1e12, "mfma_peak_tflops": 2500.0}
+
+
+def bank_binding(S, T, k_ms):
+    """k_bank's own floor (mtr_bank.hip; profiles/r06_bank.md): 28.75 VALU instructions per (frame, wave) in the compiled loop — 25 fp64
+    (19 fma, 5 add, 1 mul), a v_cvt_f32_f64, 2 fp32 fma, half a v_max3, a quarter of the loop's own — on lanes = (stream, band); a pure
+    register-to-register stream of that mix issues at 2.00 ns per wave-instruction and SIMD with four waves resident (tools/ubench64.hip on
+    the same chip: the fp64 unit under the power cap, ~1.95 GHz x 4 cycles) and the launch's 3840 waves are 3.75 per SIMD: the fullest SIMDs carry four."""
+    waves = (S * 30 + 63) // 64
+    per_simd = -(-waves // 1024)                                  # waves on the fullest SIMD
+    inst = 28.75 * T * per_simd
+    ns = 2.00
+    return {"bound": "fp64 VALU issue (25 fp64 + 3.75 other instructions per frame and band; lane = (stream, band)) on the fullest SIMDs",
+            "valu_instructions_per_frame_and_wave": 28.75, "waves": waves, "waves_on_the_fullest_simd": per_simd, "mean_waves_per_simd": waves / 1024.0,
+            "ns_per_wave_instruction_and_simd_at_4_waves": ns, "kernel_ms_at_floor": inst * ns * 1e-6,
+            "frac_of_floor": inst * ns * 1e-6 / k_ms}
+
+
 def end_to_end_host(M, torch, buf, fs, meters, device, n=1024, reps=3):
     """Host-resident audio: n streams of the benchmark's own buffers in pageable memory -> mtr_engine_process_host."""
     T = buf.shape[1]
@@ -167,9 +206,9 @@ def kernel_sha():
 def committed_traffic(meters, S, T, layout):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md):
     the counters cannot be read from inside this process, so the figure is reported only for the very workload AND the
-    very kernel sources it was measured on (profiles/r05_traffic.json carries their hash); otherwise null."""
+    very kernel sources it was measured on (profiles/r06_traffic.json carries their hash); otherwise null."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r06_traffic.json")))
         w = tj["workload"]
         if (meters, S, T, layout) == (w["meters"], w["streams_per_gpu"], w["frames_per_stream"], w["layout"]) \
                 and tj["kernel_sha16"] == kernel_sha():
@@ -549,6 +588,10 @@ def run(args, rank, local, world):
                                "kernel": {"spectr30": "k_bank", "bitstats": "k_bitstats", "sigdist": "k_sigdist",
                                           "tpb": "k_tpb", "dr14": "k_dr14_sums", "kmeter": "k_kmeter_pieces"}.get(args.meters, "k_bank"),
                                "kernel_ms": k_ms}
+            if args.meters == "tpb":
+                out["roofline"]["binding_roofline"] = tpb_binding(S, T, k_ms, 2)
+            elif args.meters == "spectr30":
+                out["roofline"]["binding_roofline"] = bank_binding(S, T, k_ms)
         if mono:
             emit(out)
             eng.close()
@@ -666,7 +709,7 @@ def run(args, rank, local, world):
             cfgs["2: 4x true peak, 1024 streams x 60 s"] = {"kernel": k["kernel"], "kernel_ms": f, "wall_ms": w, "frac": frac(1024, 60 * 48000, f),
                                                           "bound": "SIMD issue (MFMA) under the power cap"}
             _, _, bk, w, _ = timed(4096, T, M.METER_SPECTR30, steps=2)
-            cfgs["3: 30-band bank, 4096 streams x 10 s"] = {"kernel": "k_bank", "kernel_ms": bk, "wall_ms": w, "frac": frac(4096, T, bk),
+            cfgs["3: 30-band bank, 4096 streams x 10 s"] = {"kernel": "k_bank", "kernel_ms": bk, "wall_ms": w, "frac": frac(4096, T, bk), "binding_roofline": bank_binding(4096, T, bk),
                                                            "bound": "fp64 VALU (ceiling 4.2-5.0 % of HBM peak, SURVEY.md 8d)"}
             f, g, bk, w, k = timed(S, T, meters | M.METER_SPECTR30, steps=2)
             cfgs["4: EBU + true peak + bank, 8192 streams x 10 s (one of 8 shards)"] = {
@@ -684,7 +727,7 @@ def run(args, rank, local, world):
                                                                            "frac": frac(S, T44, f), "bound": "SIMD issue under the power cap"}
             _, _, bk, w, _ = timed(S, T, M.METER_TPBALLIST, steps=2)
             cfgs["true-peak ballistics (TruePeakdsp::process), 8192 streams x 10 s"] = {
-                "kernel": "k_tpb", "kernel_ms": bk, "wall_ms": w, "frac": frac(S, T, bk),
+                "kernel": "k_tpb", "kernel_ms": bk, "wall_ms": w, "frac": frac(S, T, bk), "binding_roofline": tpb_binding(S, T, bk, 2),
                 "bound": "what a SIMD can issue per 16-frame chunk: the chains (two waves: lane = (column, filter), 6.5 instructions per frame), the "
                          "products (two units per block on two waves, operands read an iteration ahead) with their maps, the split (two waves) — "
                          "VALU + matrix pipe busy 84 % of the time, three waves per SIMD, one barrier per chunk (DESIGN.md 3.5)"}

@@ -27,10 +27,13 @@ def main():
     hist = torch.zeros(2 * 751, dtype=torch.int32, device="cuda")
     mx = torch.zeros(4, dtype=torch.float32, device="cuda")
     comm = mdist.make_comm(rank, world, local)
+    assert comm.nranks() == world and comm.device() == local, (comm.nranks(), comm.device())    # RCCL's own view: N ranks, this rank's device
     with M.Engine(count, fs, M.METER_EBU | M.METER_TRUEPEAK, device=local) as e:
         e.integr_start()
+        e.set_deferred_tail(2)                                      # the gate and the all-reduce on the engine's side stream, as a batch job runs them
         e.process_device(buf.data_ptr(), T, T, st)
         e.reduce(comm, hist.data_ptr(), mx.data_ptr(), st)
+        e.sync()                                                   # (both streams)
         torch.cuda.synchronize()
     got = mdist.programme_summary(hist, mx)
     comm.close()

@@ -25,6 +25,8 @@ def test_world_of_one_is_the_identity():
     m0 = torch.zeros(4, dtype=torch.float32, device="cuda")
     h1, m1 = torch.zeros_like(h0), torch.zeros_like(m0)
     with M.Comm(0, 1, M.comm_unique_id(), 0) as comm, M.Engine(S, fs, M.METER_EBU | M.METER_TRUEPEAK) as e:
+        # what RCCL itself says about the communicator (ncclCommCount / ncclCommCuDevice): bench.py puts it into the job's line
+        assert comm.nranks() == 1 and comm.device() == 0
         e.integr_start()
         e.process_device(buf.data_ptr(), T, T, st)
         e.aggregate_device(h0.data_ptr(), m0.data_ptr(), st)
@@ -51,6 +53,7 @@ def test_world_of_one_with_a_deadline():
     with M.Comm(0, 1, M.comm_unique_id(), 0, timeout_ms=60000) as comm, M.Engine(S, fs, M.METER_EBU | M.METER_TRUEPEAK) as e:
         assert 0 < comm.init_ms < 60000
         assert 0 < comm.probe(30000) < 30000                  # the first collective, bounded
+        assert comm.nranks() == 1 and comm.device() == 0
         comm.set_timeout(20000)
         e.integr_start()
         for _ in range(3):
@@ -62,6 +65,9 @@ def test_world_of_one_with_a_deadline():
     with M.Comm(0, 1, M.comm_unique_id(), 0) as blocking:
         with pytest.raises(M.EngineError):
             blocking.set_timeout(1000)                        # a blocking communicator has no deadline to set
+    closed = M.Comm(0, 1, M.comm_unique_id(), 0, timeout_ms=20000)
+    closed.close()                                            # (finalised and destroyed, not aborted: ADVICE r5)
+    closed.close()
 
 
 def test_two_ranks_against_one_engine():
