@@ -927,16 +927,21 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	const size_t ev0 = (size_t) e->timed_calls * EV_PER_CALL;
 	if (tm) { hipEvent_t v = next_event (e, ev0); if (v) HIPCHK (hipEventRecord (v, st)); }
 
-	// the tail of this call (k_gate; the job's reduction if mtr_engine_reduce follows) on the side stream?
-	const bool defer = (ebu || tp) && (e->tail_mode == 2 || (e->tail_mode == 0 && e->v_cnt == 0 && (uint64_t) S * n_frames >= TAIL_AUTO_FRAMES));   // (auto: never the chunks of a host call — link-bound)
+	// The tail of this call (k_gate; the job's reduction if mtr_engine_reduce follows) on the side stream?  Auto: a batch whose
+	// whole fragments go through k_seg, in an engine that meters nothing else — measured (profiles/r06_tail.md): beside k_seg (issue-
+	// bound, one wave per SIMD, registers and LDS to spare) the gate costs 0.8 % less than in front of it; beside k_kw (HBM-bound,
+	// eight waves per CU) it costs 8 % MORE; behind k_bank it would start exactly when the next k_seg does; the chunks of a host
+	// call are link-bound anyway.
+	SegPlan sp;
+	if (ebu || tp) { const PlanCtx pctx = plan_ctx (e); sp = seg_plan (&pctx, d_audio, n_frames, stride); }
+	const bool only_fused = (e->cfg.meters & ~(uint32_t) (MTR_METER_EBU | MTR_METER_TRUEPEAK)) == 0;
+	const bool defer = (ebu || tp) && (e->tail_mode == 2 || (e->tail_mode == 0 && e->v_cnt == 0 && sp.use && only_fused && (uint64_t) S * n_frames >= TAIL_AUTO_FRAMES));
 	if (defer) { const int trc = tail_setup (e); if (trc) return trc; }
 	else if (ebu || tp) { const int jrc = join_tail (e, st); if (jrc) return jrc; }   // a serial gate follows the deferred ones
 	e->last_deferred = defer;
 	bool fold_in_history = false;
 
 	if (ebu || tp) {
-		const PlanCtx pctx = plan_ctx (e);
-		const SegPlan sp = seg_plan (&pctx, d_audio, n_frames, stride);
 		int rc = build_plan (e, n_frames, sp.use ? sp.head : 0, sp.use ? sp.tiles : 0, st);
 		if (rc) return rc;
 		const Plan& pl = e->plan;

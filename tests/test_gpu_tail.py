@@ -115,17 +115,20 @@ def test_mixed_modes_and_resets(M):
 
 
 def test_auto_defers_batches_only_and_join_orders_a_stream(M):
-    """mode 0: a call of >= 2^24 stream-frames is deferred, an LV2-sized one is not.  mtr_engine_join makes the caller's
-    stream wait for the side stream: a device-to-device copy of reduce ()'s buffer queued behind it sees the finished sum."""
+    """mode 0 defers where it was measured to pay (profiles/r06_tail.md): a batch whose whole fragments go through k_seg, in an
+    engine of EBU / TRUEPEAK only — not an LV2-sized call, not the EBU-only kernel (HBM-bound: the gate beside it costs more than
+    in front of it), not an engine that also runs the bank.  mtr_engine_join makes the caller's stream wait for the side stream: a
+    device-to-device copy of reduce ()'s buffer queued behind it sees the finished sum."""
     import torch
-    S, T, fs = 512, 48000, 48000.0                                     # 24.6 M stream-frames per call
+    S, T, fs = 8192, 96000, 48000.0                                    # 786 M stream-frames per call: k_seg's kind of batch
+    both = M.METER_EBU | M.METER_TRUEPEAK
+    assert M.plan_query(S, T, fs, both)["uses_seg"] == 1
     buf = torch.empty((S, T, 2), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     M.synth_fill_device(buf.data_ptr(), S, T, T, 41, fs, 1, st)
     h = torch.zeros(2 * 751, dtype=torch.int32, device="cuda")
     m = torch.zeros(4, dtype=torch.float32, device="cuda")
-    with M.Comm(0, 1, M.comm_unique_id(), 0) as comm, M.Engine(S, fs, M.METER_EBU | M.METER_TRUEPEAK) as e, \
-            M.Engine(S, fs, M.METER_EBU | M.METER_TRUEPEAK) as ser:
+    with M.Comm(0, 1, M.comm_unique_id(), 0) as comm, M.Engine(S, fs, both) as e, M.Engine(S, fs, both) as ser:
         ser.set_deferred_tail(1)
         e.integr_start(); ser.integr_start()
         copies = []
@@ -148,7 +151,15 @@ def test_auto_defers_batches_only_and_join_orders_a_stream(M):
         for (a, b), (c, d) in zip(copies, want):
             assert torch.equal(a, c) and torch.equal(b, d)
         assert int(copies[-1][0].sum()) > int(copies[0][0].sum()) > 0
-        _same(_records(M, e, M.METER_EBU | M.METER_TRUEPEAK), _records(M, ser, M.METER_EBU | M.METER_TRUEPEAK))
+        _same(_records(M, e, both), _records(M, ser, both))
+    for meters in (M.METER_EBU, both | M.METER_SPECTR30):              # the same batch: no deferral in auto, any in mode 2
+        with M.Engine(S if meters == M.METER_EBU else 256, fs, meters) as e:
+            e.integr_start()
+            e.process_device(buf.data_ptr(), T, T, st)
+            assert e.deferred_calls() == 0
+            e.set_deferred_tail(2)
+            e.process_device(buf.data_ptr(), T, T, st)
+            assert e.deferred_calls() == 1
 
 
 def test_deferred_tail_on_two_caller_streams(M):
