@@ -16,14 +16,15 @@ def md_from_summary(src, dst, title, command, kernel, bytes_per_launch, note="")
     med = None
     for line in txt.splitlines():
         if kernel in line and not line.startswith("("):
-            parts = line.split()
-            med, mn, mx, n = float(parts[-3]), float(parts[-2]), float(parts[-1]), int(parts[-4])
+            m = re.search(r"\s(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+\(avg ([0-9.]+)\)", line)
+            n, med, mn, mx, avg = int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)), float(m.group(5))
             break
     head = ["# " + title, "", "Command: " + command, ""]
     if med:
         tb = bytes_per_launch / (med * 1e-3) / 1e12
-        head += ["**`%s`: median of %d = %.4f ms (min %.4f, max %.4f: the first dispatch is cold) = %.3f TB/s = %.1f %% of the 8 TB/s HBM roofline** "
-                 "(%.2f GB of algorithmic bytes per launch)." % (kernel, n, med, mn, mx, tb, 100 * tb / 8.0, bytes_per_launch / 1e9), ""]
+        ta = bytes_per_launch / (avg * 1e-3) / 1e12
+        head += ["**`%s`: %d dispatches, AVERAGE %.4f ms = %.3f TB/s = %.1f %% of the 8 TB/s HBM roofline; median %.4f ms = %.1f %% (min %.4f, max %.4f: the first dispatch is cold)** "
+                 "(%.2f GB of algorithmic bytes per launch)." % (kernel, n, avg, ta, 100 * ta / 8.0, med, 100 * tb / 8.0, mn, mx, bytes_per_launch / 1e9), ""]
     if note:
         head += [note, ""]
     head += ["Units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles, GRBM_GUI_ACTIVE summed over the 8 XCDs; "
@@ -33,8 +34,8 @@ def md_from_summary(src, dst, title, command, kernel, bytes_per_launch, note="")
 
 
 md_from_summary("r06a_seg_ebu_tp.txt", "r06a_kseg_ebu_tp.md", "rocprofv3 summary of the headline kernel, round 6 (r06a_seg_ebu_tp)",
-                "`python bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 1` under `rocprofv3 --kernel-trace --stats` and, in separate runs, "
-                "`rocprofv3 --pmc ...` (`tools/prof_seg.sh` via `tools/r06_profiles.sh`; 7 dispatches of `k_seg`).",
+                "`python bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 5` under `rocprofv3 --kernel-trace --stats` and, in separate runs (`--steps 6 --warmup 1`), "
+                "`rocprofv3 --pmc ...` (`tools/prof_seg.sh` via `tools/r06_profiles.sh`; the kernel trace on the driver's flags `--steps 20 --warmup 5`: 25 dispatches of `k_seg`; the PMC passes on 7).",
                 "k_seg<true, true>", 8192 * 480000 * 8,
                 "`k_seg` is round 4's kernel instruction for instruction; what is new beside it is the DEFERRED TAIL: in the kernel trace `k_gate` (512 workgroups, behind "
                 "`k_delay`'s 100 us) runs on the engine's side stream beside the next `k_seg` — its 1.9 ms are elapsed time beside a kernel that owns the SIMDs, not work "
