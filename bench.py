@@ -297,7 +297,9 @@ def dry_run(args, rank, world):
     else:
         rows = [mine]
     if rank == 0:
-        emit({"dry_run": True, "n_gpus": world, "streams_per_gpu": args.streams, "ranks": [[int(v) for v in r] for r in rows]})
+        emit({"dry_run": True, "n_gpus": world, "streams_per_gpu": args.streams, "ranks": [[int(v) for v in r] for r in rows],
+              # the shape of the real line's proof of the collective (config.rccl_nranks / rank_devices): no communicator in a dry run
+              "rccl_nranks": None, "rank_devices": [{"rank": int(r[0]), "hip_device": int(r[1]), "rccl_device": None} for r in rows]})
     if world > 1:
         dist.destroy_process_group()
 
@@ -474,7 +476,10 @@ def run(args, rank, local, world):
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     per_call = eng.timing_calls()
     tq = eng.timing_query()
-    my_kernel_ms = float(per_call[:, 0].sum() + per_call[:, 1].sum()) / max(len(per_call), 1)
+    # this rank's own GPU time per step: the fused kernel + the gate — or the fused kernel alone where the gate ran deferred, inside the next
+    # step's fused kernel (its column is then elapsed time on the side stream, not time the step needed)
+    gate_cols = per_call[:, 1].sum() if eng.deferred_calls() == 0 else 0.0
+    my_kernel_ms = float(per_call[:, 0].sum() + gate_cols) / max(len(per_call), 1)
     ranks_ms = [[1e3 * t_own / args.steps, my_kernel_ms]]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)

@@ -27,6 +27,10 @@ def test_plain_python_launch_spawns_the_ranks():
     assert [r[0] for r in rows] == [0, 1] and [r[1] for r in rows] == [0, 1]          # rank, local rank = GPU ordinal
     # weak scaling: every rank owns `--streams` streams, contiguous and disjoint
     assert [r[3] for r in rows] == [101, 101] and [r[2] for r in rows] == [0, 101]
+    # the fields with which the real line proves its collective (config.rccl_nranks = ncclCommCount, per rank ncclCommCuDevice): gathered
+    # over the same control plane, one row per rank on its own device; no communicator exists in a dry run
+    assert d["rccl_nranks"] is None
+    assert sorted((x["rank"], x["hip_device"], x["rccl_device"]) for x in d["rank_devices"]) == [(0, 0, None), (1, 1, None)]
 
 
 def test_torchrun_launch_and_single_rank():
