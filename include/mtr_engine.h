@@ -162,7 +162,7 @@ int  mtr_engine_sync (mtr_engine* e);
  * and, if mtr_engine_reduce follows, the job's reduction — may run DEFERRED on an engine-owned side stream, beside the
  * fused kernel of the NEXT call instead of in front of it: that kernel needs the K-filter state and the interpolator history
  * of this call, never the gate's results.  Same kernels, same inputs, fragments inserted in fragment order: every result is
- * bit for bit that of the serial order (tests/test_gpu_tail.py).  mode 0 = auto (a batch — a call of >= 2^24 stream-frames — whose
+ * bit for bit that of the serial order (tests/test_gpu_tail.py).  mode 0 = auto (a batch — >= 4096 streams, >= 2^24 stream-frames per call — whose
  * whole fragments go through the lane = time segment kernel, in an engine of EBU / TRUEPEAK only: where it was measured to pay),
  * 1 = never (everything on the caller's stream, as the LV2-sized calls always are), 2 = always.
  * What a caller must know: results are complete when BOTH streams are — every getter, mtr_engine_sync, state export / import

@@ -181,6 +181,7 @@ struct mtr_engine {
 };
 
 constexpr int EV_PER_CALL = 6;
+constexpr uint32_t TAIL_AUTO_STREAMS = 4096;       // ... and streams per call
 constexpr uint64_t TAIL_AUTO_FRAMES = 1ull << 24;   // stream-frames per call (134 MB of stereo f32: ~40 us of the fused kernel) from which the tail is deferred
 
 static void mat4_mul (const double* a, const double* b, double* c)
@@ -935,7 +936,10 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 	SegPlan sp;
 	if (ebu || tp) { const PlanCtx pctx = plan_ctx (e); sp = seg_plan (&pctx, d_audio, n_frames, stride); }
 	const bool only_fused = (e->cfg.meters & ~(uint32_t) (MTR_METER_EBU | MTR_METER_TRUEPEAK)) == 0;
-	const bool defer = (ebu || tp) && (e->tail_mode == 2 || (e->tail_mode == 0 && e->v_cnt == 0 && sp.use && only_fused && (uint64_t) S * n_frames >= TAIL_AUTO_FRAMES));
+	// (and a batch of thousands of streams: the gate's serial time grows with the streams, what deferring it costs does not — at 1024 streams x 60 s
+	// the serial order is 0.5 % FASTER, at 8192 x 10 s the deferred one by 0.4 - 1.4 % across boxes)
+	const bool defer = (ebu || tp) && (e->tail_mode == 2 || (e->tail_mode == 0 && e->v_cnt == 0 && sp.use && only_fused && S >= TAIL_AUTO_STREAMS
+	                                                          && (uint64_t) S * n_frames >= TAIL_AUTO_FRAMES));
 	if (defer) { const int trc = tail_setup (e); if (trc) return trc; }
 	else if (ebu || tp) { const int jrc = join_tail (e, st); if (jrc) return jrc; }   // a serial gate follows the deferred ones
 	e->last_deferred = defer;
