@@ -412,6 +412,8 @@ int mtr_engine_create (const mtr_config* cfg, mtr_engine** out)
 		hipDeviceProp_t pr;
 		if (hipGetDeviceProperties (&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) { e->seg_slots = 4u * (uint32_t) pr.multiProcessorCount; e->tail_gate_grid = 2u * (uint32_t) pr.multiProcessorCount; }
 	}
+	// (test knobs: the whole -m gpu suite and the fuzzers run green with MTR_TAIL_MODE=2 — every call of every test with its tail on the side stream)
+	if (const char* v = getenv ("MTR_TAIL_MODE")) { const int m = atoi (v); if (m >= 0 && m <= 2) e->tail_mode = m; }
 	if (const char* v = getenv ("MTR_TAIL_DELAY_US")) e->tail_delay_us = (uint32_t) atoi (v);
 	if (const char* v = getenv ("MTR_TAIL_GATE_GRID")) e->tail_gate_grid = (uint32_t) atoi (v);   // (tools/r06_tail_probe.py: the experiment behind the default)
 	e->fragm = (uint32_t) ((int) cfg->sample_rate / 20);     // ebu_r128_proc.cc:170

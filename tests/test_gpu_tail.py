@@ -130,6 +130,7 @@ def test_auto_defers_batches_only_and_join_orders_a_stream(M):
     m = torch.zeros(4, dtype=torch.float32, device="cuda")
     with M.Comm(0, 1, M.comm_unique_id(), 0) as comm, M.Engine(S, fs, both) as e, M.Engine(S, fs, both) as ser:
         ser.set_deferred_tail(1)
+        e.set_deferred_tail(0)                                         # auto, whatever MTR_TAIL_MODE says (the suite also runs under MTR_TAIL_MODE=2)
         e.integr_start(); ser.integr_start()
         copies = []
         for _ in range(4):
@@ -154,6 +155,7 @@ def test_auto_defers_batches_only_and_join_orders_a_stream(M):
         _same(_records(M, e, both), _records(M, ser, both))
     for meters in (M.METER_EBU, both | M.METER_SPECTR30):              # the same batch: no deferral in auto, any in mode 2
         with M.Engine(S if meters == M.METER_EBU else 256, fs, meters) as e:
+            e.set_deferred_tail(0)
             e.integr_start()
             e.process_device(buf.data_ptr(), T, T, st)
             assert e.deferred_calls() == 0
