@@ -14,6 +14,10 @@ peak / max-loudness values (max), done once per step by mtr_engine_reduce() — 
                                                             torch.distributed.run on 127.0.0.1, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+The step's TAIL — k_gate, k_aggregate and the all-reduce of step i — runs on the engine's own side stream beside k_seg of step i + 1
+(mtr_engine_set_deferred_tail, auto for this workload; `--tail 1` keeps everything on one stream; bit for bit the same results either way:
+tests/test_gpu_tail.py); the timed region ends behind a device-wide wait, so the last step's tail is inside it.  `config.tail` says which ran.
+
 Prints ONE JSON line on rank 0.  `value` counts channel-samples/s (2 per stereo frame), whole job.
 `roofline` prices the dominant kernel (k_seg, mtr_seg.hip: K-weighting as the reference's recurrence with lane = time
 segment + the 4x interpolator on the matrix pipe at f32 grade; the layout every call of this shape takes by default) at
