@@ -168,7 +168,9 @@ int  mtr_engine_sync (mtr_engine* e);
  * What a caller must know: results are complete when BOTH streams are — every getter, mtr_engine_sync, state export / import
  * and the resets wait for both; a caller that reads d_hist / d_max of mtr_engine_reduce (or any engine buffer) in stream
  * order calls mtr_engine_join (e, stream) first: `stream` then waits for the side stream's work queued so far.
- * No reference counterpart (the reference is one instance on one thread). */
+ * No reference counterpart (the reference is one instance on one thread).
+ * (Read once by mtr_engine_create, for tests and experiments only: MTR_TAIL_MODE = the initial mode — the -m gpu suite runs green under 2 —,
+ * MTR_TAIL_DELAY_US / MTR_TAIL_GATE_GRID = the two constants of the deferred gate, see profiles/r06_tail.md.) */
 int  mtr_engine_set_deferred_tail (mtr_engine* e, int mode);
 int  mtr_engine_join (mtr_engine* e, void* hip_stream);
 /* Process calls whose tail was deferred, since the engine was created. */
