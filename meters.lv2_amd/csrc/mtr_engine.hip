@@ -111,7 +111,7 @@ struct mtr_engine {
 	// moves from the gate into k_history on the caller's stream (tp_call is already being raised by call i + 1).  Results are
 	// bit for bit those of the serial order: same kernels, same inputs, the fragment inserts in fragment order (gates follow
 	// one another on the side stream; ebumeter/ebu_r128_proc.cc:217-244).
-	int              tail_mode = 0;          // 0 auto (calls of >= TAIL_AUTO_FRAMES stream-frames), 1 never, 2 always
+	int              tail_mode = 0;          // 0 auto (a k_seg batch of >= TAIL_AUTO_STREAMS streams and >= TAIL_AUTO_FRAMES stream-frames in an EBU / TRUEPEAK engine), 1 never, 2 always
 	hipStream_t      tail_stream = nullptr;
 	hipEvent_t       ev_fused = nullptr;     // caller's stream -> side: the call's fused kernels are done
 	hipEvent_t       ev_gate[2] = { nullptr, nullptr };   // side -> caller's: the gate that read tile_power[b] is done
@@ -932,7 +932,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 
 	// The tail of this call (k_gate; the job's reduction if mtr_engine_reduce follows) on the side stream?  Auto: a batch whose
 	// whole fragments go through k_seg, in an engine that meters nothing else — measured (profiles/r06_tail.md): beside k_seg (issue-
-	// bound, one wave per SIMD, registers and LDS to spare) the gate costs 0.8 % less than in front of it; beside k_kw (HBM-bound,
+	// bound, one wave per SIMD, registers and LDS to spare) the step is 0.04 - 1.4 % shorter than with the gate in front of it; beside k_kw (HBM-bound,
 	// eight waves per CU) it costs 8 % MORE; behind k_bank it would start exactly when the next k_seg does; the chunks of a host
 	// call are link-bound anyway.
 	SegPlan sp;
@@ -1016,7 +1016,7 @@ int mtr_engine_process_device (mtr_engine* e, const float* d_audio, uint64_t n_f
 			// measured, k_seg then takes 15.4 ms instead of 9.5 (profiles/r06_tail.md) — the placement of a persistent kernel
 			// is for good.  So the side stream first idles for tail_delay_us: by then k_seg is resident (its dispatch takes
 			// ~10 us) and the gate's waves (72 VGPRs) fill in beside it (344 of 512).  Off the critical path by construction.
-			if (e->tail_delay_us && mtr_launch_delay (e->tail_delay_us, gst)) return fail (MTR_ERR_HIP, "k_delay launch");
+			if (e->tail_delay_us && mtr_launch_delay (e->tail_delay_us, gst)) { plan_abort (e, st); return fail (MTR_ERR_HIP, "k_delay launch"); }
 			e->tail_pending = true;
 			e->deferred_calls++;
 			fold_in_history = tp;
